@@ -1,0 +1,164 @@
+"""Generate tests/golden/*.npz from the IMPORTED reference -- TEST INFRASTRUCTURE ONLY.
+
+Runs only in the build container (needs ``/root/reference``); the fixtures it
+writes are committed, the reference is not.  ``pymbar`` (imported by
+``metropolisengine/statistics.py:4``, used only off the hot path) is absent
+offline and is replaced by an empty stub module.
+
+The reference is unseeded, so its random sources are replaced for the duration
+of a run by explicit streams (pin 1):
+
+  ``np.random.multivariate_normal(mean, cov, check_valid='raise')``  (real group,
+      metropolis_engine.py:268)   :=  ``mean + chol(cov) @ z_real[step]``
+  ``np.random.multivariate_normal(mean, block_cov)``  (complex group, :300)
+      :=  ``mean + [Re, Im](L w)``, ``L = chol(2 (Caa - i Cab))``, ``w = (z_re + i z_im)/sqrt 2``
+  ``random.uniform(0, 1)``  (:335)  :=  ``u[step]``
+
+Everything else -- the proposal covariances it builds, the accept rule, width
+adaptation, running mean / covariance / observables -- is the reference's own
+code.  A second set of anchors uses the reference's legacy seeded RNG unpatched.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+"""
+import math
+import os
+import random
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import scenarios                                   # noqa: E402
+from oracle.reference_chain import complex_proposal_factor     # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    for name in ("pymbar", "pymbar.timeseries"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["pymbar"].timeseries = sys.modules["pymbar.timeseries"]
+    sys.path.insert(0, "/root/reference")
+    import metropolisengine                                     # noqa: E402
+    return metropolisengine
+
+
+class InjectedStreams:
+    """Context manager swapping the reference's random sources for explicit streams."""
+
+    def __init__(self, normals, uniforms, nr, nc):
+        self.normals, self.uniforms, self.nr, self.nc = normals, uniforms, nr, nc
+        self.step = 0
+
+    def _mvn(self, mean, cov, check_valid=None, **_):
+        mean = np.asarray(mean, dtype=np.float64)
+        if check_valid == "raise":                              # the real-group call site
+            return mean + np.linalg.cholesky(cov) @ self.normals[self.step, :self.nr]
+        z = self.normals[self.step, self.nr:self.nr + 2 * self.nc]
+        w = (z[:self.nc] + 1j * z[self.nc:]) / math.sqrt(2.0)
+        v = complex_proposal_factor(np.asarray(cov)) @ w
+        return mean + np.concatenate((v.real, v.imag))
+
+    def _uniform(self, lo, hi):
+        assert (lo, hi) == (0, 1)
+        return float(self.uniforms[self.step])
+
+    def __enter__(self):
+        self._saved = (np.random.multivariate_normal, random.uniform)
+        np.random.multivariate_normal = self._mvn
+        random.uniform = self._uniform
+        return self
+
+    def __exit__(self, *exc):
+        np.random.multivariate_normal, random.uniform = self._saved
+
+
+def build_engine(me, spec, **extra):
+    kwargs = dict(initial_real_params=None if spec["real"] is None else list(spec["real"]),
+                  initial_complex_params=None if spec["cplx"] is None else list(spec["cplx"]),
+                  temp=spec["temp"])
+    kwargs.update(extra)
+    # float inputs only: integer initial values trip quirk Q8
+    if kwargs["initial_real_params"] is not None:
+        kwargs["initial_real_params"] = np.array(kwargs["initial_real_params"], dtype=np.float64)
+    if kwargs["initial_complex_params"] is not None:
+        kwargs["initial_complex_params"] = np.array(kwargs["initial_complex_params"], dtype=np.complex128)
+    engine = me.MetropolisEngine(spec["energy"], **kwargs)
+    if spec.get("reject") is not None:
+        engine.set_reject_condition(spec["reject"])            # the ctor drops it (quirk Q6)
+    return engine
+
+
+def run_scenario(me, name, spec, stream_seed):
+    nr, nc = scenarios.dims(spec)
+    total = scenarios.n_steps(spec)
+    rng = np.random.default_rng(stream_seed)
+    normals = rng.standard_normal((total, nr + 2 * nc))
+    uniforms = rng.random(total)
+    rec = {k: [] for k in ("accept", "real_params", "complex_params", "real_width", "complex_width",
+                           "energy_total", "energy_terms", "real_mean", "complex_mean", "cov_real",
+                           "cov_complex", "observables_mean")}
+    with InjectedStreams(normals, uniforms, nr, nc) as inj:
+        engine = build_engine(me, spec)
+        term_names = sorted(engine.energy)
+        for _ in range(spec["n_measures"]):
+            for _ in range(spec["steps_per_measure"]):
+                rec["accept"].append(bool(engine.step_all()))
+                inj.step += 1
+                rec["real_params"].append(np.array(engine.real_params, dtype=np.float64))
+                rec["complex_params"].append(np.array(engine.complex_params, dtype=np.complex128))
+                rec["real_width"].append(float(engine.real_group_sampling_width))
+                rec["complex_width"].append(float(engine.complex_group_sampling_width))
+                rec["energy_total"].append(float(np.real(engine.energy_total)))
+                rec["energy_terms"].append([float(np.real(engine.energy[t])) for t in term_names])
+            engine.measure()
+            rec["real_mean"].append(np.array(engine.real_mean, dtype=np.float64))
+            rec["complex_mean"].append(np.array(engine.complex_mean, dtype=np.complex128))
+            rec["cov_real"].append(np.array(engine.covariance_matrix_real, dtype=np.float64)
+                                   if nr else np.zeros((0, 0)))
+            rec["cov_complex"].append(np.array(engine.covariance_matrix_complex, dtype=np.complex128)
+                                      if nc else np.zeros((0, 0), dtype=np.complex128))
+            rec["observables_mean"].append(np.array(engine.observables_mean, dtype=np.float64))
+        consts = np.array([engine.alpha, engine.m, engine.ratio], dtype=np.float64)
+    out = {k: np.array(v) for k, v in rec.items()}
+    out.update(normals=normals, uniforms=uniforms, constants=consts,
+               term_names=np.array(term_names), stream_seed=np.array(stream_seed))
+    path = os.path.join(GOLDEN_DIR, "traj_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("%-26s steps=%5d accepts=%5d  -> %s (%d bytes)"
+          % (name, total, int(np.sum(out["accept"])), os.path.relpath(path, ROOT), os.path.getsize(path)))
+
+
+def seeded_anchors(me):
+    """Unpatched legacy-RNG runs (pin 2): 1-D only, LAPACK-independent."""
+    rows = {}
+    for seed in (12345, 7, 2026):
+        np.random.seed(seed)
+        random.seed(seed)
+        spec = scenarios.SCENARIOS["readme_1real"]
+        engine = build_engine(me, spec)
+        accepts = 0
+        for _ in range(1000):
+            accepts += bool(engine.step_all())
+            engine.measure()
+        rows[str(seed)] = np.array([accepts, engine.real_mean[0], engine.covariance_matrix_real[0, 0],
+                                    engine.real_group_sampling_width, engine.observables_mean[0],
+                                    engine.observables_mean[1], engine.real_params[0]], dtype=np.float64)
+        print("seeded anchor seed=%d: %s" % (seed, rows[str(seed)]))
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "seeded_readme_1real.npz"), **rows)
+
+
+def main():
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    me = import_reference()
+    for i, (name, spec) in enumerate(sorted(scenarios.SCENARIOS.items())):
+        run_scenario(me, name, spec, stream_seed=1000 + i)
+    seeded_anchors(me)
+
+
+if __name__ == "__main__":
+    main()
