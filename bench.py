@@ -1,0 +1,156 @@
+"""Headline benchmark: MC steps/sec (chains x sweeps), BASELINE.json config 2.
+
+    python bench.py --gpus 1 --steps 1000 --warmup 1000
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload: 16 real parameters, isotropic quadratic energy E = sum x_i^2, T = 1,
+2^20 chains PER GPU (weak scaling: chains are the independent units, sharded with no data-path collective),
+sampling_width 0.05, target acceptance 0.3, seed 2026, identity proposal shape (measure() is never called).
+One "step" = one ``step_all()`` = ONE launch of k_step advancing every chain by one propose -> energy ->
+accept/reject -> width-adaptation sweep (``--sweeps K`` fuses K sweeps per launch; reported separately as
+``fused``).  State is resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_REAL = 16
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+BYTES_PER_CHAIN_STEP = 8 * N_REAL + 16   # fp32 r/w of x[16], energy, width: SURVEY.md 8(d), B_step(identity) = 144 B
+
+
+def cpu_baseline(seconds):
+    """Python restatement of the reference loop, one chain per process on the host cores (no GPU involved)."""
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_baseline", "--seconds", str(seconds),
+                               "--seed", str(100 + i)], cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+             for i in range(cores)]
+    rate = 0.0
+    for p in procs:
+        out, _ = p.communicate()
+        rec = json.loads(out.strip().splitlines()[-1])
+        rate += rec["steps"] / rec["seconds"]
+    return {"value": rate, "unit": "chain-steps/s", "cores": cores, "kind": "port",
+            "sample": "oracle.reference_chain (pure-Python restatement of the reference step_all loop with "
+                      "np.random.multivariate_normal), config 2 (16 real, E=sum x^2, T=1), one chain per process "
+                      "on %d cores for %.0f s each; steps/s summed" % (cores, seconds)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=1000)
+    ap.add_argument("--chains-log2", type=int, default=20, help="chains per GPU = 2**this")
+    ap.add_argument("--sweeps", type=int, default=1, help="sweeps fused per launch in the headline run")
+    ap.add_argument("--fused-sweeps", type=int, default=32, help="extra fused-sweep measurement (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
+    # CPU baseline first: child processes are started before this process touches the GPU
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        cpu = cpu_baseline(args.cpu_seconds)
+
+    import torch
+    import torch.distributed as dist
+    import metropolisengine_amd as me
+    from metropolisengine_amd.distributed import pooled_statistics
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    n_local = 1 << args.chains_log2
+    engine = me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * N_REAL, None, sampling_width=0.05,
+                                 target_acceptance=0.3, temp=1.0, n_chains=n_local, seed=2026, dtype="f32",
+                                 device=local_rank, chain_offset=rank * n_local)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(n_launches, sweeps):
+        """(wall seconds, device ms from HIP events on the engine's stream) of n_launches launches."""
+        fence()
+        t0 = time.perf_counter()
+        dev_ms = engine.time_steps(n_launches, sweeps)     # enqueues, records events, waits for the stop event
+        fence()
+        wall = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall, dev_ms = float(t[0]), float(t[1])
+        return wall, dev_ms
+
+    if args.warmup > 0:
+        engine.time_steps(args.warmup, args.sweeps)
+    wall, dev_ms = timed(args.steps, args.sweeps)
+    total_chain_steps = float(n_local) * world * args.steps * args.sweeps
+    value = total_chain_steps / wall
+    kernel_ms = dev_ms / args.steps                        # average launch duration (events, same timed region)
+    algorithmic = BYTES_PER_CHAIN_STEP * n_local           # bytes one launch must move (state in, state out)
+    achieved = algorithmic / (kernel_ms * 1e-3) / 1e9
+
+    fused = None
+    if args.fused_sweeps > 0:
+        launches = max(4, args.steps // args.fused_sweeps)
+        fwall, fdev = timed(launches, args.fused_sweeps)
+        fused = {"sweeps_per_launch": args.fused_sweeps, "launches": launches,
+                 "value": float(n_local) * world * launches * args.fused_sweeps / fwall, "unit": "chain-steps/s",
+                 "ms_per_launch": fdev / launches,
+                 "effective_state_GBps": algorithmic / (fdev / launches * 1e-3) / 1e9}
+
+    stats = pooled_statistics(engine)                      # the one collective: RCCL all-reduce of pooled moments
+    engine.sync()
+
+    if rank == 0:
+        line = {
+            "metric": "MC steps/sec (chains x sweeps) at 2^20 chains, 16 params",
+            "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "config 2: 16 real params, isotropic quadratic E=sum x^2, T=1, 2^%d chains per GPU, "
+                                   "identity proposal shape, %d sweep(s) per launch, Philox4x32-10 streams"
+                                   % (args.chains_log2, args.sweeps),
+                       "chains_per_gpu": n_local, "global_chains": n_local * world, "sweeps_per_launch": args.sweeps,
+                       "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "k_step<float,16,0,EnergyIso,identity>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": algorithmic,
+                         "note": "144 B per chain-step (fp32 r/w of x[16], energy, width) x 2^%d chains / average "
+                                 "launch duration from HIP events on the engine's stream over the timed region"
+                                 % args.chains_log2},
+            "cpu_baseline": cpu,
+            "fused": fused,
+            "acceptance_rate": stats["acceptance_rate"],
+            "pooled_variance_mean": float(sum(stats["covariance"][i][i] for i in range(N_REAL)) / N_REAL),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

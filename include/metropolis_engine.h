@@ -1,0 +1,169 @@
+/*
+ * metropolis_engine.h -- C ABI of libmetropolis_hip.so, the MI355X (gfx950) many-chain Metropolis engine.
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference has no FFI: its "plugin API" is
+ * the Python class MetropolisEngine (/root/reference/metropolisengine/metropolis_engine.py:10-463).  Each
+ * entry point below replaces one piece of that class for N independent chains on one GPU; the Python class
+ * metropolisengine_amd.MetropolisEngine binds them with ctypes (see INTEGRATION.md for the stub).
+ *
+ *   me_create            <- MetropolisEngine.__init__               metropolis_engine.py:17-133
+ *   me_step              <- step_all / step_real_group / step_complex_group
+ *                           (+ draw_*_group, metropolis_decision, update_*_sigma)   :209-338, :429-456
+ *   me_measure           <- measure / measure_real_system / measure_complex_system
+ *                           (+ update_*_mean, update_covariance_matrix_*, observables) :342-427, :458-463
+ *   me_get / me_set      <- attribute reads/writes (real_params, real_mean, covariance_matrix_real, ...)
+ *                           README.md:49-51; also the only "checkpoint" the reference has (ctor warm start, :17)
+ *   me_accept_stats      <- the bool returned by step_all (:259), accumulated
+ *   me_pooled_moments*   <- no reference equivalent (ensemble estimate across chains; the one collective)
+ *   me_last_error        <- Python exceptions (:39 ValueError, :92/:438 AssertionError, numpy ValueError :270)
+ *
+ * Conventions: plain pointers and sizes only; every function returns an me_status (0 = ok); the library owns
+ * all device memory; host buffers are caller-owned.  Host-side layouts are row-major [chain][component] doubles
+ * whatever the device dtype.  Calls on one engine must not be concurrent (the reference is not reentrant
+ * either); different engines may be driven from different threads.  me_step/me_measure are asynchronous on the
+ * engine's HIP stream; me_get/me_accept_stats/me_pooled_moments synchronise that stream.
+ *
+ * State vector of one chain: D = n_real + 2*n_complex reals, ordered
+ *   [ real params | real parts of complex params | imaginary parts of complex params ].
+ */
+#ifndef METROPOLIS_ENGINE_H
+#define METROPOLIS_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ME_ABI_VERSION 1
+
+typedef struct me_engine me_engine; /* opaque handle */
+
+typedef enum me_status {
+  ME_OK = 0,
+  ME_ERR_INVALID = 1,     /* bad argument (the reference raises ValueError / AssertionError) */
+  ME_ERR_UNSUPPORTED = 2, /* no kernel compiled for this (dtype, n_real, n_complex, energy, ...) */
+  ME_ERR_HIP = 3,         /* HIP runtime error, no device, out of memory */
+  ME_ERR_NUMERIC = 4,     /* a chain produced a non-finite energy / non-positive Cholesky pivot / width */
+  ME_ERR_STATE = 5        /* call not valid in the engine's current state */
+} me_status;
+
+typedef enum me_dtype { ME_F32 = 0, ME_F64 = 1 } me_dtype;
+
+/* Energy kinds: the reference takes a Python callable (metropolis_engine.py:20, :111-120); a GPU build needs
+ * a device-side specification instead.  Coefficients are doubles, converted to the device dtype. */
+typedef enum me_energy_kind {
+  ME_ENERGY_ISO_QUAD = 0,   /* coeffs {a}: a (sum x_i^2 + sum |z_j|^2)                  README.md:26-27 */
+  ME_ENERGY_DIAG_QUAD = 1,  /* coeffs {a_0..a_{nr-1}, b_0..b_{nc-1}}: sum a x^2 + sum b |z|^2 */
+  ME_ENERGY_DENSE_QUAD = 2, /* coeffs A[D*D] row-major: x^T A x over the real D-vector */
+  ME_ENERGY_LANDAU_TOY = 3, /* coeffs {k, alpha, beta}, nr=2, nc=1   demo/toymodel_complex_and_real.py:17-26 */
+  ME_ENERGY_CYLINDER = 4    /* coeffs {kappa, gamma, wavenumber}: cylinder-style surrogate */
+} me_energy_kind;
+
+/* Hard-wall predicate evaluated before the energy (metropolis_engine.py:142-146, :247-249). */
+typedef enum me_reject_kind {
+  ME_REJECT_NONE = 0,
+  ME_REJECT_ABS_REAL0_GE = 1 /* reject when |x_0| >= reject_bound  (legacy /metropolis_engine.py:139-141) */
+} me_reject_kind;
+
+/* Which matrix shapes the proposals. */
+typedef enum me_cov_mode {
+  ME_COV_REFERENCE = 0, /* initial matrix until measure_step_counter > 50, then each chain's own running
+                           covariance (metropolis_engine.py:389, :416-427) */
+  ME_COV_FIXED = 1,     /* keep the initial matrix for ever (measure() still updates the statistics) */
+  ME_COV_POOLED = 2     /* one factor shared by all chains, installed with me_set_shared_factor */
+} me_cov_mode;
+
+/* Per-chain fields for me_get / me_set; components per chain in brackets (P = nr(nr+1)/2 + nc^2). */
+typedef enum me_field {
+  ME_FIELD_PARAMS = 0,   /* [D]  current state */
+  ME_FIELD_ENERGY = 1,   /* [1]  energy of the current state */
+  ME_FIELD_WIDTH = 2,    /* [1]  the adapting sampling width (shared width in mixed engines) */
+  ME_FIELD_MEAN = 3,     /* [D]  running mean */
+  ME_FIELD_COV = 4,      /* [P]  running covariance, packed: real block row-major lower triangle, then for
+                                 each complex row i: (Re,Im) of K_ij for j<i, then K_ii */
+  ME_FIELD_OBS_MEAN = 5, /* [2nr+nc] running mean of |x_r|, |z_c|, x_r^2 */
+  ME_FIELD_FACTOR = 6    /* [P]  Cholesky factors used by the proposals (same packing; conj(K) for complex) */
+} me_field;
+
+typedef struct me_config {
+  uint32_t abi_version; /* ME_ABI_VERSION */
+  int32_t device_id;    /* HIP device ordinal */
+  int64_t n_chains;     /* chains held by THIS engine (local shard) */
+  uint64_t chain_offset; /* global id of local chain 0: random streams are addressed by global id */
+  uint64_t seed;
+  int32_t n_real;
+  int32_t n_complex;
+  int32_t dtype;        /* me_dtype of the device state and arithmetic */
+  int32_t cov_mode;     /* me_cov_mode */
+  double temp;              /* >= 0 (metropolis_engine.py:91-92) */
+  double target_acceptance; /* reference default 0.3 */
+  double sampling_width;    /* reference default 0.05 */
+  int32_t energy_kind;      /* me_energy_kind */
+  int32_t n_energy_coeffs;
+  const double *energy_coeffs;
+  int32_t reject_kind; /* me_reject_kind */
+  int32_t reserved0;
+  double reject_bound;
+  const double *initial_params;     /* [D], broadcast to every chain */
+  const double *covariance_real;    /* [nr*nr] row-major or NULL = identity (metropolis_engine.py:63-66) */
+  const double *covariance_complex; /* [nc*nc*2] row-major (Re,Im) or NULL = identity (:67-70) */
+} me_config;
+
+int me_abi_version(void);
+
+int me_create(const me_config *config, me_engine **out);
+int me_destroy(me_engine *engine);
+
+/* n_sweeps fused propose->energy->accept->adapt sweeps over all chains in one launch; n_sweeps = 1 is one
+ * reference step_all(). */
+int me_step(me_engine *engine, int32_t n_sweeps);
+int me_measure(me_engine *engine);
+/* Test hook (float64 engines): the same step with the random draws supplied by the caller instead of Philox --
+ * normals [n_sweeps][n_chains][D] standard normals, uniforms [n_sweeps][n_chains] accept draws.  This is how the
+ * reference's golden trajectories (tests/golden/, injected-stream runs of metropolis_engine.py) are replayed
+ * through the HIP kernels.  Synchronous. */
+int me_step_injected(me_engine *engine, int32_t n_sweeps, const double *normals, const double *uniforms);
+
+int me_field_components(me_engine *engine, int32_t field, int32_t *n_components);
+/* Copy chains [chain_begin, chain_begin + n_chains) of a field to/from host doubles [chain][component]. */
+int me_get(me_engine *engine, int32_t field, int64_t chain_begin, int64_t n_chains, double *dst);
+int me_set(me_engine *engine, int32_t field, int64_t chain_begin, int64_t n_chains, const double *src);
+/* Re-evaluate the stored energies after me_set(ME_FIELD_PARAMS). */
+int me_recompute_energy(me_engine *engine);
+
+/* Robbins-Monro constants the engine derived (metropolis_engine.py:101-107): alpha, m, ratio. */
+int me_constants(me_engine *engine, double *alpha, int32_t *m, double *ratio);
+int me_counters(me_engine *engine, uint64_t *step_index, uint64_t *measure_step_counter);
+int me_set_counters(me_engine *engine, uint64_t step_index, uint64_t measure_step_counter);
+int me_accept_stats(me_engine *engine, uint64_t *accepted, uint64_t *proposed);
+
+/* Ensemble sums over the local chains, fp64:
+ *   [ n, sum x (D), sum x x^T (D(D+1)/2, row-major lower triangle), sum obs (2nr+nc), accepted, proposed ]
+ * me_pooled_moments_size gives the length.  The _device form writes into caller-provided DEVICE memory (e.g. a
+ * torch tensor) so that the caller can all-reduce it with RCCL in place; it is enqueued on the engine's stream
+ * and followed by a stream synchronise. */
+int me_pooled_moments_size(me_engine *engine, int64_t *n_doubles);
+int me_pooled_moments(me_engine *engine, double *host_out, int64_t n_doubles);
+int me_pooled_moments_device(me_engine *engine, void *device_out, int64_t n_doubles);
+/* Install the shared proposal factor of ME_COV_POOLED: packed like ME_FIELD_FACTOR, [P] doubles. */
+int me_set_shared_factor(me_engine *engine, const double *packed_factor, int64_t n_doubles);
+
+int me_sync(me_engine *engine);
+/* Use an existing HIP stream (hipStream_t passed as void*) instead of the engine's own. */
+int me_set_stream(me_engine *engine, void *hip_stream);
+/* Enqueue n_launches launches of n_sweeps sweeps bracketed by HIP events on the engine's stream and return the
+ * elapsed milliseconds (device time of the whole span). */
+int me_time_steps(me_engine *engine, int32_t n_launches, int32_t n_sweeps, float *elapsed_ms);
+
+/* Text of the last error on this engine (or of the last failed me_create when engine is NULL). */
+int me_last_error(me_engine *engine, char *buf, size_t buf_bytes);
+
+/* Capability query: 1 if a kernel set for this combination is compiled in. */
+int me_supported(int32_t dtype, int32_t n_real, int32_t n_complex, int32_t energy_kind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* METROPOLIS_ENGINE_H */

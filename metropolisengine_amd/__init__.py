@@ -1,0 +1,13 @@
+"""metropolisengine_amd: MI355X-native many-chain Metropolis engine with the MetropolisEngine API surface.
+
+``import metropolisengine_amd as me; me.MetropolisEngine(me.IsoQuadratic(1.0), initial_real_params=[0.0], temp=.01)``
+mirrors ``import metropolisengine as me`` of the reference (README.md:13-17, metropolisengine/__init__.py:1).
+The HIP library is loaded on first use of an engine; there is no CPU fallback.
+"""
+from .energy import (AbsReal0AtLeast, CylinderSurrogate, DenseQuadratic, DiagQuadratic, EnergySpec, IsoQuadratic,
+                     LandauToy, RejectSpec)
+from .engine import MetropolisEngine
+
+__all__ = ["MetropolisEngine", "EnergySpec", "IsoQuadratic", "DiagQuadratic", "DenseQuadratic", "LandauToy",
+           "CylinderSurrogate", "RejectSpec", "AbsReal0AtLeast"]
+__version__ = "0.1.0"

@@ -1,0 +1,690 @@
+// C-ABI of libmetropolis_hip.so (declared in include/metropolis_engine.h): engine lifetime, launches, field
+// transfer.  Host logic here mirrors the constructor and counters of the reference class
+// (/root/reference/metropolisengine/metropolis_engine.py:17-133); the arithmetic lives in the kernels.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "me_internal.h"
+
+namespace me {
+
+// ------------------------------------------------------------------------------------------------ registry
+static std::vector<const KernelSet *> &registry() {
+  static std::vector<const KernelSet *> sets;
+  return sets;
+}
+void register_kernel_set(const KernelSet *set) { registry().push_back(set); }
+const KernelSet *find_kernel_set(int dtype, int n_real, int n_complex) {
+  for (const KernelSet *s : registry())
+    if (s->dtype == dtype && s->n_real == n_real && s->n_complex == n_complex) return s;
+  return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------ helpers
+static thread_local std::string g_create_error;
+
+// Inverse standard normal CDF by Halley iteration on erfc (no tabulated coefficients).
+static double norm_ppf(double q) {
+  double x = 0.0;
+  // crude start: logistic approximation
+  x = std::log(q / (1.0 - q)) / 1.702;
+  for (int it = 0; it < 50; ++it) {
+    const double cdf = 0.5 * std::erfc(-x / std::sqrt(2.0));
+    const double pdf = std::exp(-0.5 * x * x) / std::sqrt(2.0 * M_PI);
+    const double f = cdf - q;
+    const double step = f / (pdf * (1.0 + 0.5 * x * f / pdf));  // Halley: f / (f' - f f''/(2 f')), f'' = -x pdf
+    x -= step;
+    if (std::fabs(step) < 1e-16 * std::max(1.0, std::fabs(x))) break;
+  }
+  return x;
+}
+
+// In-place packed Cholesky of the initial proposal matrices (host, double).  Returns false on a pivot <= 0
+// (numpy raises ValueError for a non-PSD real matrix, metropolis_engine.py:270).
+static bool host_factor(std::vector<double> &m, int nr, int nc) {
+  auto tri = [](int i, int j) { return i * (i + 1) / 2 + j; };
+  const int pr = nr * (nr + 1) / 2;
+  auto cre = [pr](int i, int j) { return pr + i * i + 2 * j; };
+  auto cim = [pr](int i, int j) { return pr + i * i + 2 * j + 1; };
+  auto cdg = [pr](int i) { return pr + i * i + 2 * i; };
+  for (int j = 0; j < nr; ++j) {
+    double s = m[tri(j, j)];
+    for (int k = 0; k < j; ++k) s -= m[tri(j, k)] * m[tri(j, k)];
+    if (!(s > 0)) return false;
+    const double dg = std::sqrt(s);
+    m[tri(j, j)] = dg;
+    for (int i = j + 1; i < nr; ++i) {
+      double t = m[tri(i, j)];
+      for (int k = 0; k < j; ++k) t -= m[tri(i, k)] * m[tri(j, k)];
+      m[tri(i, j)] = t / dg;
+    }
+  }
+  for (int j = 0; j < nc; ++j) {
+    double s = m[cdg(j)];
+    for (int k = 0; k < j; ++k) s -= m[cre(j, k)] * m[cre(j, k)] + m[cim(j, k)] * m[cim(j, k)];
+    if (!(s > 0)) return false;
+    const double dg = std::sqrt(s);
+    m[cdg(j)] = dg;
+    for (int i = j + 1; i < nc; ++i) {
+      double tr = m[cre(i, j)], ti = m[cim(i, j)];
+      for (int k = 0; k < j; ++k) {
+        const double ar = m[cre(i, k)], ai = m[cim(i, k)], br = m[cre(j, k)], bi = m[cim(j, k)];
+        tr -= ar * br + ai * bi;
+        ti -= ai * br - ar * bi;
+      }
+      m[cre(i, j)] = tr / dg;
+      m[cim(i, j)] = ti / dg;
+    }
+  }
+  return true;
+}
+
+}  // namespace me
+
+using namespace me;
+
+struct me_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  const KernelSet *ks = nullptr;
+  int dtype = ME_F32;
+  size_t esize = 4;
+  long long n = 0;
+  int nr = 0, nc = 0, d = 0, p = 0, nobs = 0;
+  unsigned long long chain_offset = 0, seed = 0;
+  double temp = 0, target_acceptance = 0.3, alpha = 0, ratio = 0, reject_bound = 0;
+  int m = 0, energy_kind = 0, reject_kind = 0, cov_mode = 0;
+  int cov_kind = CK_IDENTITY;
+  int grid_blocks = 0;
+  std::vector<double> coef;
+  unsigned long long step_index = 0, measure_count = 1;   // counters start at 1 (metropolis_engine.py:72-75)
+  // device buffers (SoA: component-major, chain-minor)
+  void *x = nullptr, *energy = nullptr, *width = nullptr, *mean = nullptr, *cov = nullptr, *obs_mean = nullptr;
+  void *factor = nullptr, *shared_factor = nullptr, *coef_dev = nullptr, *row_dev = nullptr;
+  unsigned long long *counters = nullptr;
+  unsigned int *status = nullptr;
+  double *pool_dev = nullptr;
+  std::string err;
+};
+
+namespace {
+
+int fail(me_engine *e, int code, const std::string &msg) {
+  if (e) e->err = msg;
+  else g_create_error = msg;
+  return code;
+}
+
+#define ME_HIP(e, call)                                                                                      \
+  do {                                                                                                       \
+    hipError_t err__ = (call);                                                                               \
+    if (err__ != hipSuccess)                                                                                 \
+      return fail((e), ME_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(err__));                    \
+  } while (0)
+
+void to_device_type(const double *src, size_t count, int dtype, std::vector<unsigned char> &out) {
+  out.resize(count * (dtype == ME_F32 ? 4 : 8));
+  if (dtype == ME_F32) {
+    float *o = reinterpret_cast<float *>(out.data());
+    for (size_t i = 0; i < count; ++i) o[i] = (float)src[i];
+  } else {
+    std::memcpy(out.data(), src, count * 8);
+  }
+}
+
+// broadcast one host row (doubles) to every chain of a component-major device field
+int broadcast(me_engine *e, void *dst, const std::vector<double> &row) {
+  std::vector<unsigned char> bytes;
+  to_device_type(row.data(), row.size(), e->dtype, bytes);
+  ME_HIP(e, hipMemcpyAsync(e->row_dev, bytes.data(), bytes.size(), hipMemcpyHostToDevice, e->stream));
+  ME_HIP(e, launch_broadcast_rows(dst, e->row_dev, (int)row.size(), e->n, e->dtype, e->stream));
+  ME_HIP(e, hipStreamSynchronize(e->stream));   // row_dev / bytes are reused by the next call
+  return ME_OK;
+}
+
+int field_info(me_engine *e, int field, void **ptr, int *comps) {
+  switch (field) {
+    case ME_FIELD_PARAMS: *ptr = e->x; *comps = e->d; return ME_OK;
+    case ME_FIELD_ENERGY: *ptr = e->energy; *comps = 1; return ME_OK;
+    case ME_FIELD_WIDTH: *ptr = e->width; *comps = 1; return ME_OK;
+    case ME_FIELD_MEAN: *ptr = e->mean; *comps = e->d; return ME_OK;
+    case ME_FIELD_OBS_MEAN: *ptr = e->obs_mean; *comps = e->nobs; return ME_OK;
+    case ME_FIELD_COV:
+      if (!e->cov) return fail(e, ME_ERR_UNSUPPORTED, "per-chain covariance is not compiled for these dimensions");
+      *ptr = e->cov; *comps = e->p; return ME_OK;
+    case ME_FIELD_FACTOR:
+      if (!e->factor) return fail(e, ME_ERR_UNSUPPORTED, "per-chain factors are not compiled for these dimensions");
+      *ptr = e->factor; *comps = e->p; return ME_OK;
+    default: return fail(e, ME_ERR_INVALID, "unknown field id");
+  }
+}
+
+// Surface per-chain failure flags (the analogue of the reference's exceptions) and clear them.
+int check_status(me_engine *e) {
+  unsigned int bits = 0;
+  ME_HIP(e, hipMemcpyAsync(&bits, e->status, sizeof(bits), hipMemcpyDeviceToHost, e->stream));
+  ME_HIP(e, hipStreamSynchronize(e->stream));
+  if (!bits) return ME_OK;
+  ME_HIP(e, hipMemsetAsync(e->status, 0, sizeof(unsigned int), e->stream));
+  std::string msg = "numeric failure in at least one chain:";
+  if (bits & ST_NONFINITE_ENERGY) msg += " non-finite energy;";
+  if (bits & ST_BAD_PIVOT) msg += " non-positive Cholesky pivot (proposal covariance not positive definite);";
+  if (bits & ST_BAD_WIDTH) msg += " sampling width <= 0;";
+  return fail(e, ME_ERR_NUMERIC, msg);
+}
+
+void fill_step_launch(me_engine *e, StepLaunch &l, int n_sweeps) {
+  l.x = e->x;
+  l.energy = e->energy;
+  l.width = e->width;
+  l.factor = e->cov_kind == CK_PER_CHAIN ? e->factor : e->shared_factor;
+  l.coef_device = e->coef_dev;
+  l.coef_host = e->coef.data();
+  l.n_coef = (int)e->coef.size();
+  l.inj_normals = nullptr;
+  l.inj_uniforms = nullptr;
+  l.counters = e->counters;
+  l.status = e->status;
+  l.n = e->n;
+  l.chain_offset = e->chain_offset;
+  l.step_index = e->step_index;
+  l.seed = e->seed;
+  l.n_sweeps = n_sweeps;
+  l.energy_kind = e->energy_kind;
+  l.cov_kind = e->cov_kind;
+  l.reject_kind = e->reject_kind;
+  l.grid_blocks = e->grid_blocks;
+  l.reject_bound = e->reject_bound;
+  l.temp = e->temp;
+  l.ratio = e->ratio;
+  l.target_acceptance = e->target_acceptance;
+  // step_number_factor = max(measure_step_counter / m, 200)   (metropolis_engine.py:430)
+  l.damping = std::max((double)e->measure_count / (double)e->m, 200.0);
+}
+
+void release(me_engine *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  void *bufs[] = {e->x, e->energy, e->width, e->mean, e->cov, e->obs_mean, e->factor, e->shared_factor,
+                  e->coef_dev, e->row_dev, e->counters, e->status, e->pool_dev};
+  for (void *b : bufs)
+    if (b) (void)hipFree(b);
+  if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int me_abi_version(void) { return ME_ABI_VERSION; }
+
+int me_supported(int32_t dtype, int32_t n_real, int32_t n_complex, int32_t energy_kind) {
+  const KernelSet *ks = find_kernel_set(dtype, n_real, n_complex);
+  return ks && ks->has_energy(energy_kind) ? 1 : 0;
+}
+
+int me_create(const me_config *c, me_engine **out) {
+  if (!c || !out) return fail(nullptr, ME_ERR_INVALID, "null config or output pointer");
+  *out = nullptr;
+  if (c->abi_version != ME_ABI_VERSION) return fail(nullptr, ME_ERR_INVALID, "me_config.abi_version mismatch");
+  if (c->n_real < 0 || c->n_complex < 0 || c->n_real + c->n_complex == 0)
+    return fail(nullptr, ME_ERR_INVALID,
+                "must give at least one real or complex parameter (metropolis_engine.py:37-39)");
+  if (c->n_chains <= 0) return fail(nullptr, ME_ERR_INVALID, "n_chains must be positive");
+  if (!(c->temp >= 0)) return fail(nullptr, ME_ERR_INVALID, "temp must be >= 0 (metropolis_engine.py:92)");
+  if (!(c->target_acceptance > 0 && c->target_acceptance < 1))
+    return fail(nullptr, ME_ERR_INVALID, "target_acceptance must be in (0, 1)");
+  if (!(c->sampling_width > 0)) return fail(nullptr, ME_ERR_INVALID, "sampling_width must be > 0");
+  if (c->dtype != ME_F32 && c->dtype != ME_F64) return fail(nullptr, ME_ERR_INVALID, "unknown dtype");
+  if (!c->initial_params) return fail(nullptr, ME_ERR_INVALID, "initial_params is required");
+  if (c->n_energy_coeffs < 0 || (c->n_energy_coeffs > 0 && !c->energy_coeffs))
+    return fail(nullptr, ME_ERR_INVALID, "energy coefficients missing");
+  if (c->cov_mode < ME_COV_REFERENCE || c->cov_mode > ME_COV_POOLED)
+    return fail(nullptr, ME_ERR_INVALID, "unknown cov_mode");
+  const KernelSet *ks = find_kernel_set(c->dtype, c->n_real, c->n_complex);
+  if (!ks)
+    return fail(nullptr, ME_ERR_UNSUPPORTED,
+                "no kernel set compiled for (dtype, n_real, n_complex) = (" + std::to_string(c->dtype) + ", " +
+                    std::to_string(c->n_real) + ", " + std::to_string(c->n_complex) + ")");
+  if (!ks->has_energy(c->energy_kind))
+    return fail(nullptr, ME_ERR_UNSUPPORTED, "energy kind " + std::to_string(c->energy_kind) +
+                                                  " is not compiled for these dimensions");
+  if (c->cov_mode == ME_COV_REFERENCE && !ks->per_chain_cov)
+    return fail(nullptr, ME_ERR_UNSUPPORTED,
+                "per-chain adaptive covariance is not compiled for these dimensions; use ME_COV_FIXED or ME_COV_POOLED");
+
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(nullptr, ME_ERR_HIP, "no HIP device available (this library has no CPU fallback)");
+  if (c->device_id < 0 || c->device_id >= n_dev) return fail(nullptr, ME_ERR_INVALID, "device_id out of range");
+
+  me_engine *e = new me_engine;
+  e->device = c->device_id;
+  e->ks = ks;
+  e->dtype = c->dtype;
+  e->esize = c->dtype == ME_F32 ? 4 : 8;
+  e->n = c->n_chains;
+  e->nr = c->n_real;
+  e->nc = c->n_complex;
+  e->d = e->nr + 2 * e->nc;
+  e->p = packed_total(e->nr, e->nc);
+  e->nobs = n_observables(e->nr, e->nc);
+  e->chain_offset = c->chain_offset;
+  e->seed = c->seed;
+  e->temp = c->temp;
+  e->target_acceptance = c->target_acceptance;
+  e->energy_kind = c->energy_kind;
+  e->reject_kind = c->reject_kind;
+  e->reject_bound = c->reject_bound;
+  e->cov_mode = c->cov_mode;
+  e->coef.assign(c->energy_coeffs, c->energy_coeffs + c->n_energy_coeffs);
+  // adaptation constants (metropolis_engine.py:101-107; quirks Q2 and Q4 reproduced)
+  e->alpha = -norm_ppf(c->target_acceptance / 2.0);
+  e->m = e->nr + e->nc;
+  e->ratio = (1.0 - 1.0 / e->m) * std::sqrt(2.0 * M_PI) * std::exp(e->alpha * e->alpha / 2.0) / 2.0 * e->alpha +
+             1.0 / (e->m * c->target_acceptance * (1.0 - c->target_acceptance));
+  if (const char *g = std::getenv("ME_GRID_BLOCKS")) e->grid_blocks = std::atoi(g);
+
+#define ME_CREATE_HIP(call)                                                                  \
+  do {                                                                                       \
+    hipError_t err__ = (call);                                                               \
+    if (err__ != hipSuccess) {                                                               \
+      g_create_error = std::string(#call) + ": " + hipGetErrorString(err__);                 \
+      release(e);                                                                            \
+      return ME_ERR_HIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+  ME_CREATE_HIP(hipSetDevice(e->device));
+  ME_CREATE_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  e->own_stream = true;
+  const size_t n = (size_t)e->n, es = e->esize;
+  ME_CREATE_HIP(hipMalloc(&e->x, n * e->d * es));
+  ME_CREATE_HIP(hipMalloc(&e->energy, n * es));
+  ME_CREATE_HIP(hipMalloc(&e->width, n * es));
+  ME_CREATE_HIP(hipMalloc(&e->mean, n * e->d * es));
+  ME_CREATE_HIP(hipMalloc(&e->obs_mean, n * e->nobs * es));
+  if (ks->per_chain_cov) {
+    ME_CREATE_HIP(hipMalloc(&e->cov, n * e->p * es));
+    ME_CREATE_HIP(hipMalloc(&e->factor, n * e->p * es));
+  }
+  ME_CREATE_HIP(hipMalloc(&e->shared_factor, (size_t)e->p * es));
+  ME_CREATE_HIP(hipMalloc(&e->row_dev, (size_t)std::max(std::max(e->d, e->p), e->nobs) * es));
+  ME_CREATE_HIP(hipMalloc((void **)&e->counters, 2 * sizeof(unsigned long long)));
+  ME_CREATE_HIP(hipMalloc((void **)&e->status, sizeof(unsigned int)));
+  ME_CREATE_HIP(hipMalloc((void **)&e->pool_dev, sizeof(double) * (size_t)moments_size(e->nr, e->nc)));
+  ME_CREATE_HIP(hipMemsetAsync(e->counters, 0, 2 * sizeof(unsigned long long), e->stream));
+  ME_CREATE_HIP(hipMemsetAsync(e->status, 0, sizeof(unsigned int), e->stream));
+  if (e->energy_kind == ME_ENERGY_DENSE_QUAD) {
+    std::vector<unsigned char> bytes;
+    to_device_type(e->coef.data(), e->coef.size(), e->dtype, bytes);
+    ME_CREATE_HIP(hipMalloc(&e->coef_dev, bytes.size()));
+    ME_CREATE_HIP(hipMemcpy(e->coef_dev, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+  }
+#undef ME_CREATE_HIP
+
+  // initial state: every chain starts at the caller's point (:41, :51); running means start there too (:77-78)
+  std::vector<double> init(c->initial_params, c->initial_params + e->d);
+  std::vector<double> obs(e->nobs);
+  for (int i = 0; i < e->nr; ++i) {
+    obs[i] = std::fabs(init[i]);
+    obs[e->nr + e->nc + i] = init[i] * init[i];
+  }
+  for (int j = 0; j < e->nc; ++j) obs[e->nr + j] = std::hypot(init[e->nr + j], init[e->nr + e->nc + j]);
+  // initial proposal matrices, packed (identity by default, :63-70)
+  const int pr = packed_real(e->nr);
+  std::vector<double> c0(e->p, 0.0);
+  bool identity = true;
+  for (int i = 0; i < e->nr; ++i)
+    for (int j = 0; j <= i; ++j) {
+      const double v = c->covariance_real ? c->covariance_real[i * e->nr + j] : (i == j ? 1.0 : 0.0);
+      c0[i * (i + 1) / 2 + j] = v;
+      identity = identity && v == (i == j ? 1.0 : 0.0);
+    }
+  for (int i = 0; i < e->nc; ++i) {
+    for (int j = 0; j < i; ++j) {
+      const double re = c->covariance_complex ? c->covariance_complex[2 * (i * e->nc + j)] : 0.0;
+      const double im = c->covariance_complex ? c->covariance_complex[2 * (i * e->nc + j) + 1] : 0.0;
+      c0[pr + i * i + 2 * j] = re;
+      c0[pr + i * i + 2 * j + 1] = im;
+      identity = identity && re == 0.0 && im == 0.0;
+    }
+    const double dg = c->covariance_complex ? c->covariance_complex[2 * (i * e->nc + i)] : 1.0;
+    c0[pr + i * i + 2 * i] = dg;
+    identity = identity && dg == 1.0;
+  }
+  std::vector<double> f0 = c0;
+  for (int i = 0; i < e->nc; ++i)
+    for (int j = 0; j < i; ++j) f0[pr + i * i + 2 * j + 1] = -f0[pr + i * i + 2 * j + 1];   // conj(K), quirk Q3
+  if (!host_factor(f0, e->nr, e->nc)) {
+    release(e);
+    return fail(nullptr, ME_ERR_INVALID, "initial covariance matrix is not positive definite (metropolis_engine.py:270)");
+  }
+  int rc = ME_OK;
+  std::vector<double> width_row(1, c->sampling_width);
+  if ((rc = broadcast(e, e->x, init)) || (rc = broadcast(e, e->mean, init)) || (rc = broadcast(e, e->obs_mean, obs)) ||
+      (rc = broadcast(e, e->width, width_row)) || (e->cov && (rc = broadcast(e, e->cov, c0))) ||
+      (e->factor && (rc = broadcast(e, e->factor, f0)))) {
+    g_create_error = e->err;
+    release(e);
+    return rc;
+  }
+  {
+    std::vector<unsigned char> bytes;
+    to_device_type(f0.data(), f0.size(), e->dtype, bytes);
+    if (hipMemcpy(e->shared_factor, bytes.data(), bytes.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      release(e);
+      return fail(nullptr, ME_ERR_HIP, "upload of the initial proposal factor failed");
+    }
+  }
+  e->cov_kind = identity ? CK_IDENTITY : CK_SHARED;
+
+  rc = me_recompute_energy(e);
+  if (rc == ME_OK) {
+    hipError_t herr = hipStreamSynchronize(e->stream);
+    if (herr != hipSuccess) rc = fail(e, ME_ERR_HIP, std::string("initial energy evaluation: ") + hipGetErrorString(herr));
+  }
+  if (rc != ME_OK) {
+    g_create_error = e->err;
+    release(e);
+    return rc;
+  }
+  *out = e;
+  return ME_OK;
+}
+
+int me_destroy(me_engine *e) {
+  if (!e) return ME_ERR_INVALID;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  release(e);
+  return ME_OK;
+}
+
+int me_recompute_energy(me_engine *e) {
+  if (!e) return ME_ERR_INVALID;
+  ME_HIP(e, hipSetDevice(e->device));
+  EnergyLaunch l;
+  l.x = e->x;
+  l.energy = e->energy;
+  l.coef_device = e->coef_dev;
+  l.coef_host = e->coef.data();
+  l.n_coef = (int)e->coef.size();
+  l.status = e->status;
+  l.n = e->n;
+  l.energy_kind = e->energy_kind;
+  l.grid_blocks = e->grid_blocks;
+  hipError_t err = e->ks->init_energy(l, e->stream);
+  if (err == hipErrorInvalidValue) return fail(e, ME_ERR_INVALID, "wrong number of energy coefficients for this energy kind");
+  ME_HIP(e, err);
+  return ME_OK;
+}
+
+int me_step(me_engine *e, int32_t n_sweeps) {
+  if (!e) return ME_ERR_INVALID;
+  if (n_sweeps <= 0) return fail(e, ME_ERR_INVALID, "n_sweeps must be positive");
+  ME_HIP(e, hipSetDevice(e->device));
+  StepLaunch l;
+  fill_step_launch(e, l, n_sweeps);
+  ME_HIP(e, e->ks->step(l, e->stream));
+  e->step_index += (unsigned long long)n_sweeps;
+  return ME_OK;
+}
+
+int me_step_injected(me_engine *e, int32_t n_sweeps, const double *normals, const double *uniforms) {
+  if (!e || !normals || !uniforms) return ME_ERR_INVALID;
+  if (n_sweeps <= 0) return fail(e, ME_ERR_INVALID, "n_sweeps must be positive");
+  if (e->dtype != ME_F64) return fail(e, ME_ERR_UNSUPPORTED, "injected-stream replay is compiled for float64 engines only");
+  ME_HIP(e, hipSetDevice(e->device));
+  const size_t n = (size_t)e->n, d = (size_t)e->d, k = (size_t)n_sweeps;
+  std::vector<double> zn(k * d * n), un(k * n);
+  for (size_t s = 0; s < k; ++s)
+    for (size_t c = 0; c < n; ++c) {
+      for (size_t j = 0; j < d; ++j) zn[(s * d + j) * n + c] = normals[(s * n + c) * d + j];
+      un[s * n + c] = uniforms[s * n + c];
+    }
+  double *zd = nullptr, *ud = nullptr;
+  ME_HIP(e, hipMalloc((void **)&zd, zn.size() * sizeof(double)));
+  hipError_t herr = hipMalloc((void **)&ud, un.size() * sizeof(double));
+  if (herr != hipSuccess) {
+    (void)hipFree(zd);
+    return fail(e, ME_ERR_HIP, "hipMalloc of the injected uniforms failed");
+  }
+  int rc = ME_OK;
+  if (hipMemcpy(zd, zn.data(), zn.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(ud, un.data(), un.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+    rc = fail(e, ME_ERR_HIP, "upload of the injected streams failed");
+  } else {
+    StepLaunch l;
+    fill_step_launch(e, l, n_sweeps);
+    l.inj_normals = zd;
+    l.inj_uniforms = ud;
+    herr = e->ks->step(l, e->stream);
+    if (herr == hipSuccess) herr = hipStreamSynchronize(e->stream);
+    if (herr != hipSuccess) rc = fail(e, ME_ERR_HIP, std::string("injected step: ") + hipGetErrorString(herr));
+    else e->step_index += (unsigned long long)n_sweeps;
+  }
+  (void)hipFree(zd);
+  (void)hipFree(ud);
+  return rc;
+}
+
+int me_measure(me_engine *e) {
+  if (!e) return ME_ERR_INVALID;
+  ME_HIP(e, hipSetDevice(e->device));
+  e->measure_count += 1;   // metropolis_engine.py:343
+  MeasureLaunch l;
+  l.x = e->x;
+  l.width = e->width;
+  l.mean = e->mean;
+  l.cov = e->cov;
+  l.obs_mean = e->obs_mean;
+  l.factor = e->factor;
+  l.status = e->status;
+  l.n = e->n;
+  l.measure_count = e->measure_count;
+  l.update_cov = (e->measure_count > 50 && e->cov) ? 1 : 0;   // :389, :396
+  l.write_factor = (l.update_cov && e->cov_mode == ME_COV_REFERENCE) ? 1 : 0;
+  l.grid_blocks = e->grid_blocks;
+  ME_HIP(e, e->ks->measure(l, e->stream));
+  if (l.write_factor) e->cov_kind = CK_PER_CHAIN;
+  return ME_OK;
+}
+
+int me_field_components(me_engine *e, int32_t field, int32_t *n_components) {
+  if (!e || !n_components) return ME_ERR_INVALID;
+  void *ptr;
+  int comps;
+  int rc = field_info(e, field, &ptr, &comps);
+  if (rc == ME_OK) *n_components = comps;
+  return rc;
+}
+
+int me_get(me_engine *e, int32_t field, int64_t chain_begin, int64_t n_chains, double *dst) {
+  if (!e || !dst) return ME_ERR_INVALID;
+  if (chain_begin < 0 || n_chains < 0 || chain_begin + n_chains > e->n) return fail(e, ME_ERR_INVALID, "chain range out of bounds");
+  ME_HIP(e, hipSetDevice(e->device));
+  void *ptr;
+  int comps;
+  int rc = field_info(e, field, &ptr, &comps);
+  if (rc != ME_OK) return rc;
+  if (n_chains == 0) return ME_OK;
+  std::vector<unsigned char> tmp((size_t)comps * n_chains * e->esize);
+  for (int r = 0; r < comps; ++r)
+    ME_HIP(e, hipMemcpyAsync(tmp.data() + (size_t)r * n_chains * e->esize,
+                             (const unsigned char *)ptr + ((size_t)r * e->n + chain_begin) * e->esize,
+                             (size_t)n_chains * e->esize, hipMemcpyDeviceToHost, e->stream));
+  ME_HIP(e, hipStreamSynchronize(e->stream));
+  if (e->dtype == ME_F32) {
+    const float *t = reinterpret_cast<const float *>(tmp.data());
+    for (int r = 0; r < comps; ++r)
+      for (int64_t c = 0; c < n_chains; ++c) dst[c * comps + r] = (double)t[(size_t)r * n_chains + c];
+  } else {
+    const double *t = reinterpret_cast<const double *>(tmp.data());
+    for (int r = 0; r < comps; ++r)
+      for (int64_t c = 0; c < n_chains; ++c) dst[c * comps + r] = t[(size_t)r * n_chains + c];
+  }
+  return check_status(e);
+}
+
+int me_set(me_engine *e, int32_t field, int64_t chain_begin, int64_t n_chains, const double *src) {
+  if (!e || !src) return ME_ERR_INVALID;
+  if (chain_begin < 0 || n_chains < 0 || chain_begin + n_chains > e->n) return fail(e, ME_ERR_INVALID, "chain range out of bounds");
+  ME_HIP(e, hipSetDevice(e->device));
+  void *ptr;
+  int comps;
+  int rc = field_info(e, field, &ptr, &comps);
+  if (rc != ME_OK) return rc;
+  if (n_chains == 0) return ME_OK;
+  std::vector<unsigned char> tmp((size_t)comps * n_chains * e->esize);
+  if (e->dtype == ME_F32) {
+    float *t = reinterpret_cast<float *>(tmp.data());
+    for (int r = 0; r < comps; ++r)
+      for (int64_t c = 0; c < n_chains; ++c) t[(size_t)r * n_chains + c] = (float)src[c * comps + r];
+  } else {
+    double *t = reinterpret_cast<double *>(tmp.data());
+    for (int r = 0; r < comps; ++r)
+      for (int64_t c = 0; c < n_chains; ++c) t[(size_t)r * n_chains + c] = src[c * comps + r];
+  }
+  for (int r = 0; r < comps; ++r)
+    ME_HIP(e, hipMemcpyAsync((unsigned char *)ptr + ((size_t)r * e->n + chain_begin) * e->esize,
+                             tmp.data() + (size_t)r * n_chains * e->esize, (size_t)n_chains * e->esize,
+                             hipMemcpyHostToDevice, e->stream));
+  ME_HIP(e, hipStreamSynchronize(e->stream));
+  if (field == ME_FIELD_FACTOR) e->cov_kind = CK_PER_CHAIN;
+  return ME_OK;
+}
+
+int me_constants(me_engine *e, double *alpha, int32_t *m, double *ratio) {
+  if (!e) return ME_ERR_INVALID;
+  if (alpha) *alpha = e->alpha;
+  if (m) *m = e->m;
+  if (ratio) *ratio = e->ratio;
+  return ME_OK;
+}
+
+int me_counters(me_engine *e, uint64_t *step_index, uint64_t *measure_step_counter) {
+  if (!e) return ME_ERR_INVALID;
+  if (step_index) *step_index = e->step_index;
+  if (measure_step_counter) *measure_step_counter = e->measure_count;
+  return ME_OK;
+}
+
+int me_set_counters(me_engine *e, uint64_t step_index, uint64_t measure_step_counter) {
+  if (!e) return ME_ERR_INVALID;
+  if (measure_step_counter < 1) return fail(e, ME_ERR_INVALID, "measure_step_counter starts at 1");
+  e->step_index = step_index;
+  e->measure_count = measure_step_counter;
+  return ME_OK;
+}
+
+int me_accept_stats(me_engine *e, uint64_t *accepted, uint64_t *proposed) {
+  if (!e) return ME_ERR_INVALID;
+  ME_HIP(e, hipSetDevice(e->device));
+  unsigned long long host[2] = {0, 0};
+  ME_HIP(e, hipMemcpyAsync(host, e->counters, sizeof(host), hipMemcpyDeviceToHost, e->stream));
+  ME_HIP(e, hipStreamSynchronize(e->stream));
+  if (accepted) *accepted = host[0];
+  if (proposed) *proposed = host[1];
+  return check_status(e);
+}
+
+int me_pooled_moments_size(me_engine *e, int64_t *n_doubles) {
+  if (!e || !n_doubles) return ME_ERR_INVALID;
+  *n_doubles = moments_size(e->nr, e->nc);
+  return ME_OK;
+}
+
+int me_pooled_moments_device(me_engine *e, void *device_out, int64_t n_doubles) {
+  if (!e || !device_out) return ME_ERR_INVALID;
+  if (n_doubles != moments_size(e->nr, e->nc)) return fail(e, ME_ERR_INVALID, "wrong pooled-moment buffer length");
+  ME_HIP(e, hipSetDevice(e->device));
+  hipError_t err = launch_pool_reduce(e->x, e->n, e->nr, e->nc, e->dtype, e->counters, (double *)device_out, e->stream);
+  if (err == hipErrorInvalidValue) return fail(e, ME_ERR_UNSUPPORTED, "pooled moments: dimension too large for the reduction kernel");
+  ME_HIP(e, err);
+  ME_HIP(e, hipStreamSynchronize(e->stream));
+  return ME_OK;
+}
+
+int me_pooled_moments(me_engine *e, double *host_out, int64_t n_doubles) {
+  if (!e || !host_out) return ME_ERR_INVALID;
+  int rc = me_pooled_moments_device(e, e->pool_dev, n_doubles);
+  if (rc != ME_OK) return rc;
+  ME_HIP(e, hipMemcpy(host_out, e->pool_dev, sizeof(double) * (size_t)n_doubles, hipMemcpyDeviceToHost));
+  return ME_OK;
+}
+
+int me_set_shared_factor(me_engine *e, const double *packed_factor, int64_t n_doubles) {
+  if (!e || !packed_factor) return ME_ERR_INVALID;
+  if (e->cov_mode != ME_COV_POOLED) return fail(e, ME_ERR_STATE, "me_set_shared_factor needs cov_mode = ME_COV_POOLED");
+  if (n_doubles != e->p) return fail(e, ME_ERR_INVALID, "wrong packed factor length");
+  ME_HIP(e, hipSetDevice(e->device));
+  std::vector<unsigned char> bytes;
+  to_device_type(packed_factor, (size_t)n_doubles, e->dtype, bytes);
+  ME_HIP(e, hipStreamSynchronize(e->stream));
+  ME_HIP(e, hipMemcpy(e->shared_factor, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+  e->cov_kind = CK_SHARED;
+  return ME_OK;
+}
+
+int me_sync(me_engine *e) {
+  if (!e) return ME_ERR_INVALID;
+  ME_HIP(e, hipSetDevice(e->device));
+  ME_HIP(e, hipStreamSynchronize(e->stream));
+  return check_status(e);
+}
+
+int me_set_stream(me_engine *e, void *hip_stream) {
+  if (!e) return ME_ERR_INVALID;
+  ME_HIP(e, hipSetDevice(e->device));
+  ME_HIP(e, hipStreamSynchronize(e->stream));
+  if (e->own_stream) (void)hipStreamDestroy(e->stream);
+  e->stream = (hipStream_t)hip_stream;
+  e->own_stream = false;
+  return ME_OK;
+}
+
+int me_time_steps(me_engine *e, int32_t n_launches, int32_t n_sweeps, float *elapsed_ms) {
+  if (!e || !elapsed_ms) return ME_ERR_INVALID;
+  if (n_launches <= 0 || n_sweeps <= 0) return fail(e, ME_ERR_INVALID, "n_launches and n_sweeps must be positive");
+  ME_HIP(e, hipSetDevice(e->device));
+  hipEvent_t start, stop;
+  ME_HIP(e, hipEventCreate(&start));
+  ME_HIP(e, hipEventCreate(&stop));
+  ME_HIP(e, hipEventRecord(start, e->stream));
+  for (int i = 0; i < n_launches; ++i) {
+    StepLaunch l;
+    fill_step_launch(e, l, n_sweeps);
+    hipError_t err = e->ks->step(l, e->stream);
+    if (err != hipSuccess) {
+      (void)hipEventDestroy(start);
+      (void)hipEventDestroy(stop);
+      return fail(e, ME_ERR_HIP, std::string("step launch: ") + hipGetErrorString(err));
+    }
+    e->step_index += (unsigned long long)n_sweeps;
+  }
+  ME_HIP(e, hipEventRecord(stop, e->stream));
+  ME_HIP(e, hipEventSynchronize(stop));
+  ME_HIP(e, hipEventElapsedTime(elapsed_ms, start, stop));
+  (void)hipEventDestroy(start);
+  (void)hipEventDestroy(stop);
+  return ME_OK;
+}
+
+int me_last_error(me_engine *e, char *buf, size_t buf_bytes) {
+  if (!buf || buf_bytes == 0) return ME_ERR_INVALID;
+  const std::string &s = e ? e->err : g_create_error;
+  const size_t k = std::min(buf_bytes - 1, s.size());
+  std::memcpy(buf, s.data(), k);
+  buf[k] = 0;
+  return ME_OK;
+}
+
+}  // extern "C"

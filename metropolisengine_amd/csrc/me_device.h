@@ -1,0 +1,473 @@
+// Device code of the many-chain Metropolis engine for gfx950 (MI355X): one lane owns one chain, one wavefront a
+// tile of 64 chains; the chain's state lives in registers for the whole launch.
+//
+// Reference semantics (file = /root/reference/metropolisengine/metropolis_engine.py):
+//   k_step     step_all / step_real_group / step_complex_group :209-259, draw_*_group :261-302,
+//              metropolis_decision :319-338, update_*_sigma :429-456
+//   k_measure  measure* :342-383, update_*_mean :404-410, update_covariance_matrix_* :416-427,
+//              construct_observables / update_observables_mean :458-463, :412-414
+// The random streams are the counter-based Philox4x32-10 streams specified in oracle/philox.py.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "me_internal.h"
+
+namespace me {
+
+// ------------------------------------------------------------------------------------------------ Philox
+struct U4 {
+  uint32_t x, y, z, w;
+};
+
+// Philox4x32-10 (Salmon et al. 2011; the generator of hiprand's PHILOX4_32_10).  The key schedule is
+// wave-uniform and lives in scalar registers; each round is two 32x32->64 multiplies (v_mad_u64_u32) and
+// four xors.
+__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+    U4 n;
+    n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+    n.y = (uint32_t)p1;
+    n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+    n.w = (uint32_t)p0;
+    c = n;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+
+// ------------------------------------------------------------------------------------------------ numerics
+template <typename R>
+struct Num;
+
+template <>
+struct Num<float> {
+  // u = (w + 0.5) 2^-32 in (0, 1]; Box-Muller with the hardware transcendentals: v_log_f32 is log2,
+  // v_sin_f32 / v_cos_f32 take their argument in revolutions, which is exactly 2*pi*u2.
+  static __device__ __forceinline__ float unit(uint32_t w) {
+    return __builtin_fmaf((float)w, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+  }
+  static __device__ __forceinline__ void normal_pair(uint32_t wa, uint32_t wb, float &g0, float &g1) {
+    const float u1 = unit(wa), u2 = unit(wb);
+    const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u1)
+    g0 = r * __builtin_amdgcn_cosf(u2);
+    g1 = r * __builtin_amdgcn_sinf(u2);
+  }
+  // accept an uphill move of size d > 0:  u <= exp(-d/T)
+  static __device__ __forceinline__ bool uphill(float u, float d, float temp, float inv_temp_log2e) {
+    return u <= __builtin_amdgcn_exp2f(-d * inv_temp_log2e);
+  }
+  static __device__ __forceinline__ float adapt(float w, bool acc, float ratio, float p, float damping,
+                                                float up, float down) {
+    return __builtin_fmaf(w, acc ? up : down, w);
+  }
+  static __device__ __forceinline__ float sqrt_(float v) { return __builtin_sqrtf(v); }
+  static __device__ __forceinline__ float abs_(float v) { return __builtin_fabsf(v); }
+  static __device__ __forceinline__ bool finite(float v) { return __builtin_isfinite(v); }
+};
+
+template <>
+struct Num<double> {
+  static __device__ __forceinline__ double unit(uint32_t w) { return ((double)w + 0.5) * (1.0 / 4294967296.0); }
+  static __device__ __forceinline__ void normal_pair(uint32_t wa, uint32_t wb, double &g0, double &g1) {
+    const double u1 = unit(wa), u2 = unit(wb);
+    const double r = sqrt(-2.0 * log(u1));
+    const double theta = 6.283185307179586 * u2;
+    g0 = r * cos(theta);
+    g1 = r * sin(theta);
+  }
+  static __device__ __forceinline__ bool uphill(double u, double d, double temp, double) {
+    return u <= exp(-d / temp);
+  }
+  // literal order of metropolis_engine.py:431-435 so that trajectories track the float64 oracle
+  static __device__ __forceinline__ double adapt(double w, bool acc, double ratio, double p, double damping,
+                                                 double, double) {
+    const double scale = w * ratio;
+    return acc ? w + scale * (1.0 - p) / damping : w - scale * p / damping;
+  }
+  static __device__ __forceinline__ double sqrt_(double v) { return sqrt(v); }
+  static __device__ __forceinline__ double abs_(double v) { return fabs(v); }
+  static __device__ __forceinline__ bool finite(double v) { return isfinite(v); }
+};
+
+// ------------------------------------------------------------------------------------------------ energies
+// An energy is a small by-value functor evaluated on the chain's register-resident state
+// x[D] = [real | Re z | Im z]; it stands in for the reference's Python callback (metropolis_engine.py:250).
+template <typename R, int NR, int NC>
+struct EnergyIso {  // a (sum x^2 + sum |z|^2)                                        README.md:26-27
+  static constexpr int D = NR + 2 * NC;
+  R a;
+  __device__ __forceinline__ R operator()(const R (&x)[D]) const {
+    R s = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) s += x[d] * x[d];
+    return a * s;
+  }
+};
+
+template <typename R, int NR, int NC>
+struct EnergyDiag {  // sum a_i x_i^2 + sum b_j |z_j|^2; weights expanded to D entries on the host
+  static constexpr int D = NR + 2 * NC;
+  R w[D];
+  __device__ __forceinline__ R operator()(const R (&x)[D]) const {
+    R s = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) s += w[d] * x[d] * x[d];
+    return s;
+  }
+};
+
+template <typename R, int NR, int NC>
+struct EnergyDense {  // x^T A x, A[D][D] row-major in device memory; entries are wave-uniform (scalar loads)
+  static constexpr int D = NR + 2 * NC;
+  const R *a;
+  __device__ __forceinline__ R operator()(const R (&x)[D]) const {
+    R e = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      R y = 0;
+#pragma unroll
+      for (int j = 0; j < D; ++j) y += a[i * D + j] * x[j];
+      e += x[i] * y;
+    }
+    return e;
+  }
+};
+
+template <typename R, int NR, int NC>
+struct EnergyLandau {  // k(1-x)^2 + k(1-y)^2 + x y (alpha |c|^2 + beta |c|^4)   demo/toymodel_complex_and_real.py:17-26
+  static constexpr int D = NR + 2 * NC;
+  R k, alpha, beta;
+  __device__ __forceinline__ R operator()(const R (&x)[D]) const {
+    static_assert(NR == 2 && NC == 1, "Landau toy is 2 real + 1 complex");
+    const R a2 = x[2] * x[2] + x[3] * x[3];
+    const R ox = R(1) - x[0], oy = R(1) - x[1];
+    return k * ox * ox + k * oy * oy + x[0] * x[1] * (alpha * a2 + beta * a2 * a2);
+  }
+};
+
+template <typename R, int NR, int NC>
+struct EnergyCylinder {  // cylinder-style surrogate, see oracle/energies.py:cylinder_surrogate and DESIGN.md
+  static constexpr int D = NR + 2 * NC;
+  R kappa, gamma, wavenumber;
+  __device__ __forceinline__ R operator()(const R (&x)[D]) const {
+    static_assert(NR >= 1 && NC >= 1, "cylinder surrogate needs an amplitude and a field");
+    R s = 0;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) s += x[i] * x[i];
+    const R x0 = x[0];
+    const R surface = kappa * s / (R(1) - x0 * x0);
+    const R amp = R(1) + R(0.5) * x0 * x0;
+    R field = 0, tot = 0;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const R q = wavenumber * (R(j) - R(NC - 1) * R(0.5));
+      const R mod2 = x[NR + j] * x[NR + j] + x[NR + NC + j] * x[NR + NC + j];
+      field += (gamma + q * q * amp) * mod2;
+      tot += mod2;
+    }
+    return surface + field + R(0.5) * tot * tot;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ k_step
+template <typename R>
+struct StepArgs {
+  R *x, *energy, *width;
+  const R *factor;
+  const R *inj_normals;   // INJECT only: [sweep][D][n] standard normals replacing the Philox draws
+  const R *inj_uniforms;  // INJECT only: [sweep][n] accept uniforms
+  unsigned long long *counters;
+  unsigned int *status;
+  long long n;
+  unsigned long long chain_offset, step_index;
+  uint32_t seed_lo, seed_hi;
+  int n_sweeps, reject_kind;
+  R reject_bound, temp, inv_temp_log2e, ratio, p, damping, up, down;
+};
+
+// packed index of element (i, j), j <= i, of a row-major lower triangle
+__host__ __device__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+// complex block (after the PR real entries): row i holds (Re,Im) of columns j < i, then the real diagonal
+__host__ __device__ constexpr int cre(int pr, int i, int j) { return pr + i * i + 2 * j; }
+__host__ __device__ constexpr int cim(int pr, int i, int j) { return pr + i * i + 2 * j + 1; }
+__host__ __device__ constexpr int cdiag(int pr, int i) { return pr + i * i + 2 * i; }
+
+// INJECT = true replaces the Philox draws by caller-provided streams (test hook: replays the reference's golden
+// trajectories, tests/golden/, through the very same proposal / accept / adapt code).
+template <typename R, int NR, int NC, class Energy, int CK, bool INJECT = false>
+__global__ void __launch_bounds__(kBlockThreads) k_step(StepArgs<R> a, Energy en) {
+  constexpr int D = NR + 2 * NC;
+  constexpr int PR = NR * (NR + 1) / 2;
+  constexpr int NW = 2 * ((D + 1) / 2);     // words consumed by the Box-Muller pairs
+  constexpr int NBLK = (NW + 1 + 3) / 4;    // Philox blocks per step (word NW is the accept uniform)
+  using N_ = Num<R>;
+
+  unsigned int wave_accepted = 0, wave_proposed = 0;
+  bool bad_energy = false, bad_width = false;
+  const long long stride = (long long)gridDim.x * kBlockThreads;
+  for (long long c = (long long)blockIdx.x * kBlockThreads + threadIdx.x; c < a.n; c += stride) {
+    R x[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = a.x[(long long)d * a.n + c];
+    R e = a.energy[c];
+    R w = a.width[c];
+    const unsigned long long gid = a.chain_offset + (unsigned long long)c;
+    // CK_PER_CHAIN reads element k at factor[k*n + c] (coalesced); CK_SHARED reads factor[k] (wave-uniform)
+    auto fac = [&](int k) -> R {
+      if constexpr (CK == CK_PER_CHAIN) return a.factor[(long long)k * a.n + c];
+      else return a.factor[k];
+    };
+
+    for (int s = 0; s < a.n_sweeps; ++s) {
+      const unsigned long long step = a.step_index + (unsigned long long)s;
+      R g[NW];
+      R u;
+      if constexpr (INJECT) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) g[j] = a.inj_normals[((long long)s * D + j) * a.n + c];
+        u = a.inj_uniforms[(long long)s * a.n + c];
+      } else {
+        uint32_t words[4 * NBLK];
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+          U4 ctr;
+          ctr.x = (uint32_t)gid;
+          ctr.y = (uint32_t)(gid >> 32);
+          ctr.z = (uint32_t)step;
+          ctr.w = ((uint32_t)(step >> 32) << 16) | (uint32_t)b;
+          const U4 o = philox4x32_10(ctr, a.seed_lo, a.seed_hi);
+          words[4 * b + 0] = o.x;
+          words[4 * b + 1] = o.y;
+          words[4 * b + 2] = o.z;
+          words[4 * b + 3] = o.w;
+        }
+#pragma unroll
+        for (int q = 0; q < NW / 2; ++q) N_::normal_pair(words[2 * q], words[2 * q + 1], g[2 * q], g[2 * q + 1]);
+        u = N_::unit(words[NW]);
+      }
+
+      // ---- proposal: x' = x + w L_r g_r ; z' = z + w L_c (g_re + i g_im)/sqrt2   (:261-302)
+      R xp[D];
+      if constexpr (CK == CK_IDENTITY) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) xp[i] = x[i] + w * g[i];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+          xp[NR + j] = x[NR + j] + w * (g[NR + j] * R(0.70710678118654752440));
+          xp[NR + NC + j] = x[NR + NC + j] + w * (g[NR + NC + j] * R(0.70710678118654752440));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          R acc = 0;
+#pragma unroll
+          for (int j = 0; j <= i; ++j) acc += fac(tri(i, j)) * g[j];
+          xp[i] = x[i] + w * acc;
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+          R are = 0, aim = 0;
+#pragma unroll
+          for (int j = 0; j < i; ++j) {
+            const R lre = fac(cre(PR, i, j));
+            const R lim = fac(cim(PR, i, j));
+            const R wre = g[NR + j] * R(0.70710678118654752440), wim = g[NR + NC + j] * R(0.70710678118654752440);
+            are += lre * wre - lim * wim;
+            aim += lre * wim + lim * wre;
+          }
+          const R ld = fac(cdiag(PR, i));
+          are += ld * (g[NR + i] * R(0.70710678118654752440));
+          aim += ld * (g[NR + NC + i] * R(0.70710678118654752440));
+          xp[NR + i] = x[NR + i] + w * are;
+          xp[NR + NC + i] = x[NR + NC + i] + w * aim;
+        }
+      }
+
+      // ---- hard wall before the energy (:247-249), energy, accept rule (:319-338)
+      bool rejected = false;
+      if (a.reject_kind == ME_REJECT_ABS_REAL0_GE) rejected = !(N_::abs_(xp[0]) < a.reject_bound);
+      const R e_new = en(xp);
+      const R diff = e_new - e;
+      bool accept = diff <= R(0);
+      if (a.temp > R(0)) accept = accept || N_::uphill(u, diff, a.temp, a.inv_temp_log2e);
+      accept = accept && !rejected;
+      bad_energy |= (!rejected && !N_::finite(e_new));
+#pragma unroll
+      for (int d = 0; d < D; ++d) x[d] = accept ? xp[d] : x[d];
+      e = accept ? e_new : e;
+      // ---- Robbins-Monro width update (:429-456)
+      w = N_::adapt(w, accept, a.ratio, a.p, a.damping, a.up, a.down);
+      wave_accepted += (unsigned int)__popcll(__ballot(accept));
+    }
+    bad_width |= !(w > R(0));
+#pragma unroll
+    for (int d = 0; d < D; ++d) a.x[(long long)d * a.n + c] = x[d];
+    a.energy[c] = e;
+    a.width[c] = w;
+    wave_proposed += (unsigned int)__popcll(__ballot(true)) * (unsigned int)a.n_sweeps;
+  }
+  // acceptance tracking: ballot + popcount per sweep, one atomic pair per wavefront per launch
+  if ((threadIdx.x & 63) == 0 && wave_proposed) {
+    atomicAdd(&a.counters[0], (unsigned long long)wave_accepted);
+    atomicAdd(&a.counters[1], (unsigned long long)wave_proposed);
+  }
+  const unsigned int bits = (bad_energy ? ST_NONFINITE_ENERGY : 0u) | (bad_width ? ST_BAD_WIDTH : 0u);
+  if (bits) atomicOr(a.status, bits);
+}
+
+template <typename R, int NR, int NC, class Energy>
+__global__ void __launch_bounds__(kBlockThreads) k_init_energy(const R *xs, R *energy, long long n, unsigned int *status,
+                                                                Energy en) {
+  constexpr int D = NR + 2 * NC;
+  const long long stride = (long long)gridDim.x * kBlockThreads;
+  for (long long c = (long long)blockIdx.x * kBlockThreads + threadIdx.x; c < n; c += stride) {
+    R x[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = xs[(long long)d * n + c];
+    const R e = en(x);
+    energy[c] = e;
+    if (!Num<R>::finite(e)) atomicOr(status, (unsigned int)ST_NONFINITE_ENERGY);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ k_measure
+template <typename R>
+struct MeasureArgs {
+  const R *x, *width;
+  R *mean, *cov, *obs_mean, *factor;
+  unsigned int *status;
+  long long n;
+  R keep;      // (i-1)/i
+  R inv_i;     // 1/i
+  R cov_keep;  // (i-2)/(i-1)
+  int update_cov, write_factor;
+};
+
+// Running mean, Haario-type covariance recursion with the reference's undivided epsilon term (quirk Q1),
+// observables, and the refresh of the packed Cholesky factors the next proposals use.
+// The covariance update is the algebraically identical one-pass form
+//     C <- C (i-2)/(i-1) + (x - mu_old)(x - mu_old)^H / i + (sigma^2 / i) I
+// of metropolis_engine.py:416-427 (mu_old mu_old^H - i/(i-1) mu mu^H + x x^H/(i-1) == delta delta^H / i),
+// which has no cancellation when |mean| >> std and is therefore safe in fp32.
+template <typename R, int NR, int NC, bool PER_CHAIN_COV>
+__global__ void __launch_bounds__(kBlockThreads) k_measure(MeasureArgs<R> a) {
+  constexpr int D = NR + 2 * NC;
+  constexpr int PR = NR * (NR + 1) / 2;
+  constexpr int P = PR + NC * NC;
+  constexpr int NOBS = 2 * NR + NC;
+  using N_ = Num<R>;
+  bool bad_pivot = false;
+  const long long stride = (long long)gridDim.x * kBlockThreads;
+  for (long long c = (long long)blockIdx.x * kBlockThreads + threadIdx.x; c < a.n; c += stride) {
+    R x[D], delta[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      x[d] = a.x[(long long)d * a.n + c];
+      const R mu = a.mean[(long long)d * a.n + c];
+      delta[d] = x[d] - mu;
+      a.mean[(long long)d * a.n + c] = mu * a.keep + x[d] * a.inv_i;   // :404-410
+    }
+    // observables [|x_r|, |z_c|, x_r^2] and their running mean (:458-463, :412-414)
+#pragma unroll
+    for (int k = 0; k < NOBS; ++k) {
+      R o;
+      if (k < NR) o = N_::abs_(x[k]);
+      else if (k < NR + NC) o = N_::sqrt_(x[k] * x[k] + x[k + NC] * x[k + NC]);
+      else o = x[k - NR - NC] * x[k - NR - NC];
+      const R m = a.obs_mean[(long long)k * a.n + c];
+      a.obs_mean[(long long)k * a.n + c] = m * a.keep + o * a.inv_i;
+    }
+    if constexpr (PER_CHAIN_COV) {
+      if (a.update_cov) {
+        const R w = a.width[c];
+        const R eps = w * w * a.inv_i;   // :418, :425 -- the shared width in mixed engines (:436-437)
+        R m[P];
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j) {
+            const int k = tri(i, j);
+            R v = a.cov[(long long)k * a.n + c] * a.cov_keep + delta[i] * delta[j] * a.inv_i;
+            if (i == j) v += eps;
+            a.cov[(long long)k * a.n + c] = v;
+            m[k] = v;
+          }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+          const R ai = delta[NR + i], bi = delta[NR + NC + i];
+#pragma unroll
+          for (int j = 0; j < i; ++j) {
+            const R aj = delta[NR + j], bj = delta[NR + NC + j];
+            const int kr = cre(PR, i, j), ki = cim(PR, i, j);
+            const R vr = a.cov[(long long)kr * a.n + c] * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
+            const R vi = a.cov[(long long)ki * a.n + c] * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
+            a.cov[(long long)kr * a.n + c] = vr;
+            a.cov[(long long)ki * a.n + c] = vi;
+            m[kr] = vr;
+            m[ki] = -vi;   // the proposals use conj(K) (quirk Q3, :292-298)
+          }
+          const int kd = cdiag(PR, i);
+          const R vd = a.cov[(long long)kd * a.n + c] * a.cov_keep + (ai * ai + bi * bi) * a.inv_i + eps;
+          a.cov[(long long)kd * a.n + c] = vd;
+          m[kd] = vd;
+        }
+        if (a.write_factor) {
+          // in-register Cholesky, real block
+#pragma unroll
+          for (int j = 0; j < NR; ++j) {
+            R s = m[tri(j, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= m[tri(j, k)] * m[tri(j, k)];
+            if (!(s > R(0))) { bad_pivot = true; s = R(1e-30); }
+            const R dg = N_::sqrt_(s);
+            const R inv = R(1) / dg;
+            m[tri(j, j)] = dg;
+#pragma unroll
+            for (int i = j + 1; i < NR; ++i) {
+              R t = m[tri(i, j)];
+#pragma unroll
+              for (int k = 0; k < j; ++k) t -= m[tri(i, k)] * m[tri(j, k)];
+              m[tri(i, j)] = t * inv;
+            }
+          }
+          // complex Hermitian block: L L^H = conj(K)
+#pragma unroll
+          for (int j = 0; j < NC; ++j) {
+            R s = m[cdiag(PR, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= m[cre(PR, j, k)] * m[cre(PR, j, k)] + m[cim(PR, j, k)] * m[cim(PR, j, k)];
+            if (!(s > R(0))) { bad_pivot = true; s = R(1e-30); }
+            const R dg = N_::sqrt_(s);
+            const R inv = R(1) / dg;
+            m[cdiag(PR, j)] = dg;
+#pragma unroll
+            for (int i = j + 1; i < NC; ++i) {
+              R tr = m[cre(PR, i, j)], ti = m[cim(PR, i, j)];
+#pragma unroll
+              for (int k = 0; k < j; ++k) {
+                // t -= L_ik conj(L_jk)
+                const R ar = m[cre(PR, i, k)], ai2 = m[cim(PR, i, k)];
+                const R br = m[cre(PR, j, k)], bi2 = m[cim(PR, j, k)];
+                tr -= ar * br + ai2 * bi2;
+                ti -= ai2 * br - ar * bi2;
+              }
+              m[cre(PR, i, j)] = tr * inv;
+              m[cim(PR, i, j)] = ti * inv;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < P; ++k) a.factor[(long long)k * a.n + c] = m[k];
+        }
+      }
+    }
+  }
+  if (bad_pivot) atomicOr(a.status, (unsigned int)ST_BAD_PIVOT);
+}
+
+}  // namespace me

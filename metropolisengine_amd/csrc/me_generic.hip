@@ -1,0 +1,167 @@
+// Dimension-independent kernels: broadcast fill and the ensemble (pooled) moment reduction.
+#include "me_internal.h"
+
+namespace me {
+namespace {
+
+template <typename R>
+__global__ void __launch_bounds__(kBlockThreads) k_broadcast_rows(R *dst, const R *row_values, int rows, long long n) {
+  const long long stride = (long long)gridDim.x * kBlockThreads;
+  for (long long c = (long long)blockIdx.x * kBlockThreads + threadIdx.x; c < n; c += stride)
+    for (int r = 0; r < rows; ++r) dst[(long long)r * n + c] = row_values[r];
+}
+
+constexpr int kTileChains = 64;   // chains staged per LDS tile
+constexpr int kTilePitch = 65;    // +1 pad: threads walk different rows at the same column
+constexpr int kMaxEntries = 12;   // moment entries per thread -> up to 3072 entries per engine
+
+// k_pool_reduce: S = sum over chains of [1, x, x x^T (lower), |x_r|, |z_c|, x_r^2] in fp64.
+// A block stages a tile of 64 chains x (D + nr + nc) augmented rows in LDS; every thread owns a fixed set of
+// output entries and walks the tile's 64 columns for each; per-block partial sums go out as fp64 atomics
+// (global_atomic_add_f64), one per entry per block.  Output order: me_pooled_moments in the public header.
+template <typename R>
+__global__ void __launch_bounds__(kBlockThreads) k_pool_reduce(const R *x, long long n, int nr, int nc,
+                                                               const unsigned long long *counters, double *out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  R *tile = reinterpret_cast<R *>(smem_raw);
+  const int d = nr + 2 * nc;
+  const int n_aug = d + nr + nc;
+  const int n_pair = d * (d + 1) / 2;
+  const int n_entries = 1 + n_aug + n_pair;
+  const int tid = threadIdx.x;
+
+  // decode this thread's entries once: kind 0 = count, 1 = row sum, 2 = pair product
+  int row_i[kMaxEntries], row_j[kMaxEntries], out_idx[kMaxEntries], out_idx2[kMaxEntries];
+  double acc[kMaxEntries];
+#pragma unroll
+  for (int k = 0; k < kMaxEntries; ++k) {
+    const int e = tid + k * kBlockThreads;
+    acc[k] = 0.0;
+    row_i[k] = row_j[k] = -1;
+    out_idx[k] = out_idx2[k] = -1;
+    if (e >= n_entries) continue;
+    if (e == 0) {
+      out_idx[k] = 0;
+    } else if (e <= n_aug) {
+      const int r = e - 1;
+      row_i[k] = r;
+      if (r < d) out_idx[k] = 1 + r;                                  // sum x
+      else out_idx[k] = 1 + d + n_pair + (r - d);                     // sum |x_r|, sum |z_c|
+    } else {
+      const int p = e - 1 - n_aug;
+      int i = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+      while (i * (i + 1) / 2 > p) --i;
+      while ((i + 1) * (i + 2) / 2 <= p) ++i;
+      const int j = p - i * (i + 1) / 2;
+      row_i[k] = i;
+      row_j[k] = j;
+      out_idx[k] = 1 + d + p;
+      if (i == j && i < nr) out_idx2[k] = 1 + d + n_pair + nr + nc + i;  // sum x_r^2 (observable)
+    }
+  }
+
+  const long long n_tiles = (n + kTileChains - 1) / kTileChains;
+  for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const long long base = t * kTileChains;
+    const int valid = (int)((n - base) < kTileChains ? (n - base) : kTileChains);
+    // stage: thread (r, col) pattern; 256 threads cover 4 rows x 64 columns per pass
+    for (int r = tid / kTileChains; r < n_aug; r += kBlockThreads / kTileChains) {
+      const int col = tid % kTileChains;
+      R v = 0;
+      if (col < valid) {
+        const long long c = base + col;
+        if (r < d) v = x[(long long)r * n + c];
+        else if (r < d + nr) {
+          const R xv = x[(long long)(r - d) * n + c];
+          v = xv < 0 ? -xv : xv;
+        } else {
+          const int j = r - d - nr;
+          const R re = x[(long long)(nr + j) * n + c], im = x[(long long)(nr + nc + j) * n + c];
+          v = (R)sqrt((double)re * re + (double)im * im);
+        }
+      }
+      tile[r * kTilePitch + col] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kMaxEntries; ++k) {
+      if (out_idx[k] < 0) continue;
+      if (row_i[k] < 0) {
+        acc[k] += (double)valid;
+      } else if (row_j[k] < 0) {
+        const R *ri = tile + row_i[k] * kTilePitch;
+        double s = 0.0;
+        for (int col = 0; col < kTileChains; ++col) s += (double)ri[col];
+        acc[k] += s;
+      } else {
+        const R *ri = tile + row_i[k] * kTilePitch;
+        const R *rj = tile + row_j[k] * kTilePitch;
+        double s = 0.0;
+        for (int col = 0; col < kTileChains; ++col) s += (double)ri[col] * (double)rj[col];
+        acc[k] += s;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < kMaxEntries; ++k) {
+    if (out_idx[k] < 0) continue;
+    atomicAdd(&out[out_idx[k]], acc[k]);
+    if (out_idx2[k] >= 0) atomicAdd(&out[out_idx2[k]], acc[k]);
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    const long long size = moments_size(nr, nc);
+    out[size - 2] = (double)counters[0];
+    out[size - 1] = (double)counters[1];
+  }
+}
+
+}  // namespace
+
+hipError_t launch_broadcast_rows(void *dst, const void *row_values, int rows, long long n, int dtype,
+                                 hipStream_t stream) {
+  long long blocks = (n + kBlockThreads - 1) / kBlockThreads;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  if (dtype == ME_F32)
+    hipLaunchKernelGGL(k_broadcast_rows<float>, dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream, (float *)dst,
+                       (const float *)row_values, rows, n);
+  else
+    hipLaunchKernelGGL(k_broadcast_rows<double>, dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream, (double *)dst,
+                       (const double *)row_values, rows, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_pool_reduce(const void *x, long long n, int nr, int nc, int dtype, const unsigned long long *counters,
+                              double *out_device, hipStream_t stream) {
+  const int d = nr + 2 * nc;
+  const int n_aug = d + nr + nc;
+  const int n_entries = 1 + n_aug + d * (d + 1) / 2;
+  if (n_entries > kMaxEntries * kBlockThreads) return hipErrorInvalidValue;
+  const size_t elem = dtype == ME_F32 ? sizeof(float) : sizeof(double);
+  const size_t lds = (size_t)n_aug * kTilePitch * elem;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  hipError_t err = hipMemsetAsync(out_device, 0, sizeof(double) * (size_t)moments_size(nr, nc), stream);
+  if (err != hipSuccess) return err;
+  long long tiles = (n + kTileChains - 1) / kTileChains;
+  long long blocks = tiles < 1024 ? tiles : 1024;
+  if (blocks < 1) blocks = 1;
+  if (dtype == ME_F32) {
+    if (lds > 64 * 1024) {
+      err = hipFuncSetAttribute((const void *)k_pool_reduce<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (err != hipSuccess) return err;
+    }
+    hipLaunchKernelGGL(k_pool_reduce<float>, dim3((unsigned)blocks), dim3(kBlockThreads), lds, stream, (const float *)x, n,
+                       nr, nc, counters, out_device);
+  } else {
+    if (lds > 64 * 1024) {
+      err = hipFuncSetAttribute((const void *)k_pool_reduce<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (err != hipSuccess) return err;
+    }
+    hipLaunchKernelGGL(k_pool_reduce<double>, dim3((unsigned)blocks), dim3(kBlockThreads), lds, stream, (const double *)x,
+                       n, nr, nc, counters, out_device);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace me

@@ -1,0 +1,91 @@
+// Internal interface between the C-ABI layer (me_api.hip) and the per-dimension kernel sets
+// (me_kernels.hip compiled once per (n_real, n_complex)).  Not installed; the public ABI is
+// include/metropolis_engine.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/metropolis_engine.h"
+
+namespace me {
+
+// How the step kernel obtains the proposal shape.
+enum CovKind { CK_IDENTITY = 0, CK_SHARED = 1, CK_PER_CHAIN = 2 };
+
+enum StatusBits : uint32_t {
+  ST_NONFINITE_ENERGY = 1u,  // a proposed state that was not wall-rejected had a non-finite energy
+  ST_BAD_PIVOT = 2u,         // Cholesky pivot <= 0 while refreshing a proposal factor
+  ST_BAD_WIDTH = 4u          // sampling width <= 0 or non-finite (metropolis_engine.py:438)
+};
+
+constexpr int kBlockThreads = 256;  // 4 wavefronts; one lane owns one chain
+constexpr int kMaxCoeffs = 8;       // small by-value coefficient sets (dense matrices travel by pointer)
+
+// Type-erased launch descriptors; scalars are doubles and are narrowed by the typed launcher.
+struct StepLaunch {
+  void *x, *energy, *width;
+  const void *factor;        // CK_PER_CHAIN: [P][N]; CK_SHARED: [P]
+  const void *coef_device;   // energy coefficients in device memory (device dtype)
+  const double *coef_host;   // same, host doubles
+  int n_coef;
+  const void *inj_normals;   // non-null: injected streams (f64 kernels only), [sweep][D][n] and [sweep][n]
+  const void *inj_uniforms;
+  unsigned long long *counters;  // [0] accepted, [1] proposed
+  unsigned int *status;
+  long long n;
+  unsigned long long chain_offset, step_index, seed;
+  int n_sweeps, energy_kind, cov_kind, reject_kind, grid_blocks;
+  double reject_bound, temp, ratio, target_acceptance, damping;
+};
+
+struct MeasureLaunch {
+  void *x, *width, *mean, *cov, *obs_mean, *factor;
+  unsigned int *status;
+  long long n;
+  unsigned long long measure_count;  // value AFTER the increment (metropolis_engine.py:343)
+  int update_cov;                    // measure_count > 50 (:389, :396)
+  int write_factor;                  // refresh the per-chain Cholesky factors
+  int grid_blocks;
+};
+
+struct EnergyLaunch {
+  void *x, *energy;
+  const void *coef_device;
+  const double *coef_host;
+  int n_coef;
+  unsigned int *status;
+  long long n;
+  int energy_kind, grid_blocks;
+};
+
+struct KernelSet {
+  int dtype, n_real, n_complex;
+  bool per_chain_cov;  // measure can refresh per-chain factors / step can read them
+  bool (*has_energy)(int energy_kind);
+  hipError_t (*step)(const StepLaunch &, hipStream_t);
+  hipError_t (*measure)(const MeasureLaunch &, hipStream_t);
+  hipError_t (*init_energy)(const EnergyLaunch &, hipStream_t);
+};
+
+void register_kernel_set(const KernelSet *set);
+const KernelSet *find_kernel_set(int dtype, int n_real, int n_complex);
+
+// ---- dimension-independent kernels (me_generic.hip) -------------------------------------------------------
+// dst[r*n + c] = row_values[r] for r < rows, c < n   (broadcast one chain's vector to all chains)
+hipError_t launch_broadcast_rows(void *dst, const void *row_values, int rows, long long n, int dtype,
+                                 hipStream_t stream);
+// Ensemble sums (see me_pooled_moments in the public header).  out must hold moments_size doubles and is
+// zeroed by the launcher; counters are appended by the caller.
+hipError_t launch_pool_reduce(const void *x, long long n, int n_real, int n_complex, int dtype,
+                              const unsigned long long *counters, double *out_device, hipStream_t stream);
+
+__host__ __device__ inline int packed_real(int nr) { return nr * (nr + 1) / 2; }
+__host__ __device__ inline int packed_total(int nr, int nc) { return nr * (nr + 1) / 2 + nc * nc; }
+__host__ __device__ inline int n_observables(int nr, int nc) { return 2 * nr + nc; }
+__host__ __device__ inline long long moments_size(int nr, int nc) {
+  const int d = nr + 2 * nc;
+  return 1 + d + (long long)d * (d + 1) / 2 + n_observables(nr, nc) + 2;
+}
+
+}  // namespace me

@@ -1,0 +1,199 @@
+// One kernel set per (n_real, n_complex): compiled once per pair with -DME_NR=.. -DME_NC=.. (see build.py), for
+// both device dtypes, and self-registered with the C-ABI layer at load time.
+//   -DME_DENSE=1     also instantiate the dense quadratic-form energy (x^T A x)
+//   -DME_PER_CHAIN=0 omit the per-chain covariance/factor kernels (packed matrix too large for registers)
+#include <type_traits>
+
+#include "me_device.h"
+
+#ifndef ME_NR
+#error "compile with -DME_NR=<n_real> -DME_NC=<n_complex>"
+#endif
+#ifndef ME_DENSE
+#define ME_DENSE 0
+#endif
+#ifndef ME_PER_CHAIN
+#define ME_PER_CHAIN 1
+#endif
+
+namespace me {
+namespace {
+
+constexpr int NR = ME_NR;
+constexpr int NC = ME_NC;
+[[maybe_unused]] constexpr int D = NR + 2 * NC;
+constexpr bool kLandau = (NR == 2 && NC == 1);
+constexpr bool kCylinder = (NR >= 1 && NC >= 1);
+
+bool has_energy(int kind) {
+  switch (kind) {
+    case ME_ENERGY_ISO_QUAD:
+    case ME_ENERGY_DIAG_QUAD: return true;
+    case ME_ENERGY_DENSE_QUAD: return ME_DENSE != 0;
+    case ME_ENERGY_LANDAU_TOY: return kLandau;
+    case ME_ENERGY_CYLINDER: return kCylinder;
+    default: return false;
+  }
+}
+
+inline int grid_for(long long n, int requested) {
+  long long blocks = (n + kBlockThreads - 1) / kBlockThreads;
+  if (requested > 0 && blocks > requested) blocks = requested;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+template <typename R>
+StepArgs<R> typed(const StepLaunch &l) {
+  StepArgs<R> a;
+  a.x = (R *)l.x;
+  a.energy = (R *)l.energy;
+  a.width = (R *)l.width;
+  a.factor = (const R *)l.factor;
+  a.inj_normals = (const R *)l.inj_normals;
+  a.inj_uniforms = (const R *)l.inj_uniforms;
+  a.counters = l.counters;
+  a.status = l.status;
+  a.n = l.n;
+  a.chain_offset = l.chain_offset;
+  a.step_index = l.step_index;
+  a.seed_lo = (uint32_t)l.seed;
+  a.seed_hi = (uint32_t)(l.seed >> 32);
+  a.n_sweeps = l.n_sweeps;
+  a.reject_kind = l.reject_kind;
+  a.reject_bound = (R)l.reject_bound;
+  a.temp = (R)l.temp;
+  a.inv_temp_log2e = l.temp > 0 ? (R)(1.4426950408889634 / l.temp) : (R)0;
+  a.ratio = (R)l.ratio;
+  a.p = (R)l.target_acceptance;
+  a.damping = (R)l.damping;
+  a.up = (R)(l.ratio * (1.0 - l.target_acceptance) / l.damping);
+  a.down = (R)(-l.ratio * l.target_acceptance / l.damping);
+  return a;
+}
+
+template <typename R, class Energy>
+hipError_t step_with(const StepLaunch &l, const Energy &en, hipStream_t stream) {
+  const StepArgs<R> a = typed<R>(l);
+  const dim3 grid(grid_for(l.n, l.grid_blocks)), block(kBlockThreads);
+  if (l.inj_normals) {
+    // injected-stream replay: float64 only (it exists to check trajectories against the float64 reference)
+    if constexpr (std::is_same<R, double>::value) {
+      switch (l.cov_kind) {
+        case CK_IDENTITY: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_IDENTITY, true>), grid, block, 0, stream, a, en); break;
+        case CK_SHARED: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_SHARED, true>), grid, block, 0, stream, a, en); break;
+#if ME_PER_CHAIN
+        case CK_PER_CHAIN: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_PER_CHAIN, true>), grid, block, 0, stream, a, en); break;
+#endif
+        default: return hipErrorInvalidValue;
+      }
+      return hipGetLastError();
+    } else {
+      return hipErrorNotSupported;
+    }
+  }
+  switch (l.cov_kind) {
+    case CK_IDENTITY: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_IDENTITY>), grid, block, 0, stream, a, en); break;
+    case CK_SHARED: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_SHARED>), grid, block, 0, stream, a, en); break;
+#if ME_PER_CHAIN
+    case CK_PER_CHAIN: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_PER_CHAIN>), grid, block, 0, stream, a, en); break;
+#endif
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// Build the by-value energy functor from the coefficient list and hand it to `f`.
+template <typename R, class F>
+hipError_t with_energy(int kind, const double *coef, int n_coef, const void *coef_device, F &&f) {
+  switch (kind) {
+    case ME_ENERGY_ISO_QUAD: {
+      if (n_coef != 1) return hipErrorInvalidValue;
+      EnergyIso<R, NR, NC> en{(R)coef[0]};
+      return f(en);
+    }
+    case ME_ENERGY_DIAG_QUAD: {
+      if (n_coef != NR + NC) return hipErrorInvalidValue;
+      EnergyDiag<R, NR, NC> en;
+      for (int i = 0; i < NR; ++i) en.w[i] = (R)coef[i];
+      for (int j = 0; j < NC; ++j) en.w[NR + j] = en.w[NR + NC + j] = (R)coef[NR + j];
+      return f(en);
+    }
+#if ME_DENSE
+    case ME_ENERGY_DENSE_QUAD: {
+      if (n_coef != D * D || !coef_device) return hipErrorInvalidValue;
+      EnergyDense<R, NR, NC> en{(const R *)coef_device};
+      return f(en);
+    }
+#endif
+    case ME_ENERGY_LANDAU_TOY: {
+      if constexpr (kLandau) {
+        if (n_coef != 3) return hipErrorInvalidValue;
+        EnergyLandau<R, NR, NC> en{(R)coef[0], (R)coef[1], (R)coef[2]};
+        return f(en);
+      }
+      return hipErrorInvalidValue;
+    }
+    case ME_ENERGY_CYLINDER: {
+      if constexpr (kCylinder) {
+        if (n_coef != 3) return hipErrorInvalidValue;
+        EnergyCylinder<R, NR, NC> en{(R)coef[0], (R)coef[1], (R)coef[2]};
+        return f(en);
+      }
+      return hipErrorInvalidValue;
+    }
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <typename R>
+hipError_t step(const StepLaunch &l, hipStream_t stream) {
+  return with_energy<R>(l.energy_kind, l.coef_host, l.n_coef, l.coef_device,
+                        [&](const auto &en) { return step_with<R>(l, en, stream); });
+}
+
+template <typename R>
+hipError_t init_energy(const EnergyLaunch &l, hipStream_t stream) {
+  return with_energy<R>(l.energy_kind, l.coef_host, l.n_coef, l.coef_device, [&](const auto &en) {
+    using Energy = std::decay_t<decltype(en)>;
+    hipLaunchKernelGGL((k_init_energy<R, NR, NC, Energy>), dim3(grid_for(l.n, l.grid_blocks)), dim3(kBlockThreads), 0,
+                       stream, (const R *)l.x, (R *)l.energy, l.n, l.status, en);
+    return hipGetLastError();
+  });
+}
+
+template <typename R>
+hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
+  MeasureArgs<R> a;
+  a.x = (const R *)l.x;
+  a.width = (const R *)l.width;
+  a.mean = (R *)l.mean;
+  a.cov = (R *)l.cov;
+  a.obs_mean = (R *)l.obs_mean;
+  a.factor = (R *)l.factor;
+  a.status = l.status;
+  a.n = l.n;
+  const double i = (double)l.measure_count;
+  a.keep = (R)((i - 1.0) / i);
+  a.inv_i = (R)(1.0 / i);
+  a.cov_keep = (R)((i - 2.0) / (i - 1.0));
+  a.update_cov = l.update_cov;
+  a.write_factor = l.write_factor;
+  hipLaunchKernelGGL((k_measure<R, NR, NC, ME_PER_CHAIN != 0>), dim3(grid_for(l.n, l.grid_blocks)), dim3(kBlockThreads), 0,
+                     stream, a);
+  return hipGetLastError();
+}
+
+const KernelSet kSetF32 = {ME_F32, NR, NC, ME_PER_CHAIN != 0, has_energy, step<float>, measure<float>, init_energy<float>};
+const KernelSet kSetF64 = {ME_F64, NR, NC, ME_PER_CHAIN != 0, has_energy, step<double>, measure<double>,
+                           init_energy<double>};
+
+struct Registrar {
+  Registrar() {
+    register_kernel_set(&kSetF32);
+    register_kernel_set(&kSetF64);
+  }
+} registrar;
+
+}  // namespace
+}  // namespace me

@@ -1,0 +1,110 @@
+"""Multi-GPU layer: chains shard with no data-path exchange; one small all-reduce pools the ensemble moments.
+
+One process per GPU (``torch.distributed``, backend ``nccl`` = RCCL over xGMI on ROCm; ``gloo`` in the CPU tests).
+Chains are the independent units: rank ``r`` of ``W`` owns the global chain ids ``[offset_r, offset_r + count_r)``
+and the Philox streams are addressed by global id, so results do not depend on ``W``.  The only collective is a
+sum all-reduce of the fp64 moment vector (1.5 KB at D=16, 18 KB at D=64): latency-bound, issued once per
+``pooled_statistics`` call and never per step.  The reference has no counterpart (it runs one chain in one
+process); this is the "RCCL all-reduce only for the pooled covariance/observables" of BASELINE.json.
+"""
+import numpy as np
+
+
+def shard_chains(n_total, rank, world_size):
+    """Contiguous block partition of ``n_total`` global chain ids: returns ``(offset, count)`` for ``rank``."""
+    if not 0 <= rank < world_size:
+        raise ValueError("rank out of range")
+    base, extra = divmod(int(n_total), int(world_size))
+    count = base + (1 if rank < extra else 0)
+    offset = rank * base + min(rank, extra)
+    return offset, count
+
+
+def moments_size(n_real, n_complex):
+    d = n_real + 2 * n_complex
+    return 1 + d + d * (d + 1) // 2 + 2 * n_real + n_complex + 2
+
+
+def allreduce_moments(moments, group=None):
+    """Sum a moment vector over all ranks, in place.
+
+    ``moments`` is a ``torch.Tensor`` (float64; CUDA for RCCL, CPU for gloo) or a numpy array (reduced through a CPU
+    tensor).  With no initialised process group this is the identity (single-GPU runs).
+    """
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return moments
+    if isinstance(moments, np.ndarray):
+        t = torch.from_numpy(moments)
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            moments[...] = t.cpu().numpy()
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return moments
+    dist.all_reduce(moments, op=dist.ReduceOp.SUM, group=group)
+    return moments
+
+
+def moments_to_statistics(moments, n_real, n_complex):
+    """Convert raw summed moments ``(n, sum x, sum x x^T, sum obs, accepted, proposed)`` to ensemble statistics."""
+    m = np.asarray(moments, dtype=np.float64)
+    d = n_real + 2 * n_complex
+    n_pair = d * (d + 1) // 2
+    n_obs = 2 * n_real + n_complex
+    if m.shape[0] != moments_size(n_real, n_complex):
+        raise ValueError("moment vector has the wrong length")
+    n = m[0]
+    mean = m[1:1 + d] / n
+    second = np.zeros((d, d))
+    il = np.tril_indices(d)
+    second[il] = m[1 + d:1 + d + n_pair]
+    second = second + np.tril(second, -1).T
+    cov = second / n - np.outer(mean, mean)
+    obs = m[1 + d + n_pair:1 + d + n_pair + n_obs] / n
+    accepted, proposed = m[-2], m[-1]
+    return {"n_chains": int(round(n)), "mean": mean, "covariance": cov, "observables_mean": obs,
+            "acceptance_rate": accepted / proposed if proposed else float("nan")}
+
+
+def pooled_statistics(engine, group=None):
+    """Ensemble mean / covariance / observables over ALL ranks' chains of ``engine`` (one all-reduce)."""
+    import torch
+    import torch.distributed as dist
+    nr, nc = engine.num_real_params, engine.num_complex_params
+    size = moments_size(nr, nc)
+    if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl":
+        buf = torch.empty(size, dtype=torch.float64, device="cuda")
+        engine.pooled_moments_into(buf.data_ptr(), size)          # k_pool_reduce straight into the RCCL buffer
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        total = buf.cpu().numpy()
+    else:
+        total = allreduce_moments(engine.pooled_moments(), group)
+    return moments_to_statistics(total, nr, nc)
+
+
+def pooled_factor(covariance, n_real, n_complex, jitter=0.0):
+    """Packed proposal factor (ME_FIELD_FACTOR layout) from a pooled real-representation covariance [D, D].
+
+    The real block is ``chol(C_rr)``; the complex block is built from the circular part of the pooled covariance,
+    ``K = (C_aa + C_bb) + i (C_ba - C_ab)``, and factored as ``chol(conj(K))`` like the per-chain path
+    (metropolis_engine.py:292-298).
+    """
+    nr, nc = n_real, n_complex
+    c = np.asarray(covariance, dtype=np.float64)
+    packed = []
+    if nr:
+        lr = np.linalg.cholesky(c[:nr, :nr] + jitter * np.identity(nr))
+        packed.extend(lr[np.tril_indices(nr)])
+    if nc:
+        a = slice(nr, nr + nc)
+        b = slice(nr + nc, nr + 2 * nc)
+        k = (c[a, a] + c[b, b]) + 1j * (c[b, a] - c[a, b])
+        lc = np.linalg.cholesky(np.conj(k) + jitter * np.identity(nc))
+        for i in range(nc):
+            for j in range(i):
+                packed.extend((lc[i, j].real, lc[i, j].imag))
+            packed.append(lc[i, i].real)
+    return np.asarray(packed, dtype=np.float64)

@@ -1,0 +1,94 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every symbol include/metropolis_engine.h
+declares, reports capabilities, and fails loudly without a GPU (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from metropolisengine_amd import _capi, energy
+from metropolisengine_amd.engine import MetropolisEngine, unpack_complex_block, unpack_real_block
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "metropolis_engine.h")).read()
+    return sorted(set(re.findall(r"^\s*(?:int|const char \*)\s+(me_[a-z_]+)\s*\(", text, flags=re.M)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _capi.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), "libmetropolis_hip.so does not export %s" % name
+    assert sorted(_capi.SYMBOLS) == declared, "ctypes binding and header disagree"
+    assert lib.me_abi_version() == _capi.ABI_VERSION
+
+
+def test_config_struct_layout_matches_header():
+    # natural C layout of struct me_config on x86-64
+    assert ctypes.sizeof(_capi.MeConfig) == 128
+    assert _capi.MeConfig.n_chains.offset == 8 and _capi.MeConfig.temp.offset == 48
+    assert _capi.MeConfig.energy_coeffs.offset == 80 and _capi.MeConfig.covariance_complex.offset == 120
+
+
+def test_capability_query():
+    lib = _capi.load()
+    for nr, nc in [(1, 0), (2, 0), (16, 0), (64, 0), (4, 4), (2, 1), (2, 7), (0, 1)]:
+        for dt in (_capi.ME_F32, _capi.ME_F64):
+            assert lib.me_supported(dt, nr, nc, _capi.ENERGY_ISO_QUAD) == 1
+            assert lib.me_supported(dt, nr, nc, _capi.ENERGY_DIAG_QUAD) == 1
+    assert lib.me_supported(_capi.ME_F32, 2, 1, _capi.ENERGY_LANDAU_TOY) == 1
+    assert lib.me_supported(_capi.ME_F32, 16, 0, _capi.ENERGY_LANDAU_TOY) == 0
+    assert lib.me_supported(_capi.ME_F32, 64, 0, _capi.ENERGY_DENSE_QUAD) == 1
+    assert lib.me_supported(_capi.ME_F32, 2, 7, _capi.ENERGY_CYLINDER) == 1
+    assert lib.me_supported(_capi.ME_F32, 5, 5, _capi.ENERGY_ISO_QUAD) == 0
+
+
+def test_argument_errors_match_the_reference():
+    with pytest.raises(ValueError):                      # metropolis_engine.py:37-39
+        MetropolisEngine(energy.IsoQuadratic())
+    with pytest.raises(AssertionError):                  # :92
+        MetropolisEngine(energy.IsoQuadratic(), initial_real_params=[0.0], temp=-1.0)
+    with pytest.raises(TypeError):                       # Python callables cannot run on the GPU
+        MetropolisEngine(lambda r, c: r[0] ** 2, initial_real_params=[0.0])
+    with pytest.raises(NotImplementedError):
+        MetropolisEngine(energy.IsoQuadratic(), initial_complex_params=[0j], complex_sample_method="magnitude-phase")
+    with pytest.raises(ValueError):
+        MetropolisEngine(energy.DiagQuadratic(a=[1.0]), initial_real_params=[0.0, 0.0])
+
+
+def test_create_validation_without_gpu():
+    """me_create validates its arguments before touching the device; on a GPU-less host a valid config then fails
+    loudly with ME_ERR_HIP instead of falling back to the CPU."""
+    lib = _capi.load()
+    cfg = _capi.MeConfig()
+    handle = ctypes.c_void_p()
+    assert lib.me_create(ctypes.byref(cfg), ctypes.byref(handle)) == _capi.ME_ERR_INVALID   # abi_version 0
+    assert "abi_version" in _capi.last_error()
+    init = np.zeros(5)
+    coef = np.ones(1)
+    cfg.abi_version, cfg.n_chains, cfg.n_real, cfg.n_complex = _capi.ABI_VERSION, 8, 5, 0
+    cfg.target_acceptance, cfg.sampling_width = 0.3, 0.05
+    cfg.n_energy_coeffs = 1
+    cfg.energy_coeffs = coef.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    cfg.initial_params = init.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    assert lib.me_create(ctypes.byref(cfg), ctypes.byref(handle)) == _capi.ME_ERR_UNSUPPORTED  # no (5,0) kernels
+    cfg.n_real = 16
+    cfg.temp = -1.0
+    assert lib.me_create(ctypes.byref(cfg), ctypes.byref(handle)) == _capi.ME_ERR_INVALID
+    assert "temp" in _capi.last_error()
+
+
+def test_packed_layout_helpers():
+    nr, nc = 3, 2
+    pr = nr * (nr + 1) // 2
+    packed = np.arange(1.0, pr + nc * nc + 1.0)[None, :]
+    real = unpack_real_block(packed, nr)[0]
+    assert np.array_equal(real, real.T) and real[2, 1] == packed[0, 4] and real[0, 0] == 1.0
+    cplx = unpack_complex_block(packed, nr, nc)[0]
+    assert cplx[0, 0] == packed[0, pr] and cplx[1, 0] == packed[0, pr + 1] + 1j * packed[0, pr + 2]
+    assert cplx[0, 1] == np.conj(cplx[1, 0]) and cplx[1, 1] == packed[0, pr + 3]
