@@ -107,7 +107,9 @@ struct me_engine {
   // device buffers (SoA: component-major, chain-minor)
   void *x = nullptr, *energy = nullptr, *width = nullptr, *mean = nullptr, *cov = nullptr, *obs_mean = nullptr;
   void *factor = nullptr, *shared_factor = nullptr, *coef_dev = nullptr, *row_dev = nullptr;
-  unsigned long long *counters = nullptr;
+  unsigned long long *accept_slots = nullptr, *accept_total = nullptr;
+  long long n_slots = 0;
+  unsigned long long proposed = 0;
   unsigned int *status = nullptr;
   double *pool_dev = nullptr;
   std::string err;
@@ -189,7 +191,7 @@ void fill_step_launch(me_engine *e, StepLaunch &l, int n_sweeps) {
   l.n_coef = (int)e->coef.size();
   l.inj_normals = nullptr;
   l.inj_uniforms = nullptr;
-  l.counters = e->counters;
+  l.accept_slots = e->accept_slots;
   l.status = e->status;
   l.n = e->n;
   l.chain_offset = e->chain_offset;
@@ -212,7 +214,7 @@ void release(me_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   void *bufs[] = {e->x, e->energy, e->width, e->mean, e->cov, e->obs_mean, e->factor, e->shared_factor,
-                  e->coef_dev, e->row_dev, e->counters, e->status, e->pool_dev};
+                  e->coef_dev, e->row_dev, e->accept_slots, e->accept_total, e->status, e->pool_dev};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -317,10 +319,12 @@ int me_create(const me_config *c, me_engine **out) {
   }
   ME_CREATE_HIP(hipMalloc(&e->shared_factor, (size_t)e->p * es));
   ME_CREATE_HIP(hipMalloc(&e->row_dev, (size_t)std::max(std::max(e->d, e->p), e->nobs) * es));
-  ME_CREATE_HIP(hipMalloc((void **)&e->counters, 2 * sizeof(unsigned long long)));
+  e->n_slots = (long long)grid_for(e->n, e->grid_blocks) * (kBlockThreads / 64);
+  ME_CREATE_HIP(hipMalloc((void **)&e->accept_slots, (size_t)e->n_slots * sizeof(unsigned long long)));
+  ME_CREATE_HIP(hipMalloc((void **)&e->accept_total, sizeof(unsigned long long)));
   ME_CREATE_HIP(hipMalloc((void **)&e->status, sizeof(unsigned int)));
   ME_CREATE_HIP(hipMalloc((void **)&e->pool_dev, sizeof(double) * (size_t)moments_size(e->nr, e->nc)));
-  ME_CREATE_HIP(hipMemsetAsync(e->counters, 0, 2 * sizeof(unsigned long long), e->stream));
+  ME_CREATE_HIP(hipMemsetAsync(e->accept_slots, 0, (size_t)e->n_slots * sizeof(unsigned long long), e->stream));
   ME_CREATE_HIP(hipMemsetAsync(e->status, 0, sizeof(unsigned int), e->stream));
   if (e->energy_kind == ME_ENERGY_DENSE_QUAD) {
     std::vector<unsigned char> bytes;
@@ -435,6 +439,7 @@ int me_step(me_engine *e, int32_t n_sweeps) {
   fill_step_launch(e, l, n_sweeps);
   ME_HIP(e, e->ks->step(l, e->stream));
   e->step_index += (unsigned long long)n_sweeps;
+    e->proposed += (unsigned long long)e->n * (unsigned long long)n_sweeps;
   return ME_OK;
 }
 
@@ -469,7 +474,10 @@ int me_step_injected(me_engine *e, int32_t n_sweeps, const double *normals, cons
     herr = e->ks->step(l, e->stream);
     if (herr == hipSuccess) herr = hipStreamSynchronize(e->stream);
     if (herr != hipSuccess) rc = fail(e, ME_ERR_HIP, std::string("injected step: ") + hipGetErrorString(herr));
-    else e->step_index += (unsigned long long)n_sweeps;
+    else {
+      e->step_index += (unsigned long long)n_sweeps;
+      e->proposed += (unsigned long long)e->n * (unsigned long long)n_sweeps;
+    }
   }
   (void)hipFree(zd);
   (void)hipFree(ud);
@@ -588,11 +596,12 @@ int me_set_counters(me_engine *e, uint64_t step_index, uint64_t measure_step_cou
 int me_accept_stats(me_engine *e, uint64_t *accepted, uint64_t *proposed) {
   if (!e) return ME_ERR_INVALID;
   ME_HIP(e, hipSetDevice(e->device));
-  unsigned long long host[2] = {0, 0};
-  ME_HIP(e, hipMemcpyAsync(host, e->counters, sizeof(host), hipMemcpyDeviceToHost, e->stream));
+  unsigned long long host = 0;
+  ME_HIP(e, launch_sum_slots(e->accept_slots, e->n_slots, e->accept_total, e->stream));
+  ME_HIP(e, hipMemcpyAsync(&host, e->accept_total, sizeof(host), hipMemcpyDeviceToHost, e->stream));
   ME_HIP(e, hipStreamSynchronize(e->stream));
-  if (accepted) *accepted = host[0];
-  if (proposed) *proposed = host[1];
+  if (accepted) *accepted = host;
+  if (proposed) *proposed = e->proposed;
   return check_status(e);
 }
 
@@ -606,7 +615,9 @@ int me_pooled_moments_device(me_engine *e, void *device_out, int64_t n_doubles) 
   if (!e || !device_out) return ME_ERR_INVALID;
   if (n_doubles != moments_size(e->nr, e->nc)) return fail(e, ME_ERR_INVALID, "wrong pooled-moment buffer length");
   ME_HIP(e, hipSetDevice(e->device));
-  hipError_t err = launch_pool_reduce(e->x, e->n, e->nr, e->nc, e->dtype, e->counters, (double *)device_out, e->stream);
+  ME_HIP(e, launch_sum_slots(e->accept_slots, e->n_slots, e->accept_total, e->stream));
+  hipError_t err = launch_pool_reduce(e->x, e->n, e->nr, e->nc, e->dtype, e->accept_total, (double)e->proposed,
+                                      (double *)device_out, e->stream);
   if (err == hipErrorInvalidValue) return fail(e, ME_ERR_UNSUPPORTED, "pooled moments: dimension too large for the reduction kernel");
   ME_HIP(e, err);
   ME_HIP(e, hipStreamSynchronize(e->stream));
@@ -669,6 +680,7 @@ int me_time_steps(me_engine *e, int32_t n_launches, int32_t n_sweeps, float *ela
       return fail(e, ME_ERR_HIP, std::string("step launch: ") + hipGetErrorString(err));
     }
     e->step_index += (unsigned long long)n_sweeps;
+    e->proposed += (unsigned long long)e->n * (unsigned long long)n_sweeps;
   }
   ME_HIP(e, hipEventRecord(stop, e->stream));
   ME_HIP(e, hipEventSynchronize(stop));

@@ -21,7 +21,8 @@ constexpr int kMaxEntries = 12;   // moment entries per thread -> up to 3072 ent
 // (global_atomic_add_f64), one per entry per block.  Output order: me_pooled_moments in the public header.
 template <typename R>
 __global__ void __launch_bounds__(kBlockThreads) k_pool_reduce(const R *x, long long n, int nr, int nc,
-                                                               const unsigned long long *counters, double *out) {
+                                                               const unsigned long long *accepted_total, double proposed,
+                                                               double *out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R *tile = reinterpret_cast<R *>(smem_raw);
   const int d = nr + 2 * nc;
@@ -111,8 +112,8 @@ __global__ void __launch_bounds__(kBlockThreads) k_pool_reduce(const R *x, long 
   }
   if (blockIdx.x == 0 && tid == 0) {
     const long long size = moments_size(nr, nc);
-    out[size - 2] = (double)counters[0];
-    out[size - 1] = (double)counters[1];
+    out[size - 2] = (double)accepted_total[0];
+    out[size - 1] = proposed;
   }
 }
 
@@ -132,8 +133,30 @@ hipError_t launch_broadcast_rows(void *dst, const void *row_values, int rows, lo
   return hipGetLastError();
 }
 
-hipError_t launch_pool_reduce(const void *x, long long n, int nr, int nc, int dtype, const unsigned long long *counters,
-                              double *out_device, hipStream_t stream) {
+// One block sums the per-wavefront acceptance slots (at most a few 10^4 of them).
+__global__ void __launch_bounds__(kBlockThreads) k_sum_slots(const unsigned long long *slots, long long n_slots,
+                                                             unsigned long long *total) {
+  __shared__ unsigned long long part[kBlockThreads];
+  unsigned long long s = 0;
+  for (long long i = threadIdx.x; i < n_slots; i += kBlockThreads) s += slots[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = kBlockThreads / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) total[0] = part[0];
+}
+
+hipError_t launch_sum_slots(const unsigned long long *slots, long long n_slots, unsigned long long *total,
+                            hipStream_t stream) {
+  hipLaunchKernelGGL(k_sum_slots, dim3(1), dim3(kBlockThreads), 0, stream, slots, n_slots, total);
+  return hipGetLastError();
+}
+
+hipError_t launch_pool_reduce(const void *x, long long n, int nr, int nc, int dtype,
+                              const unsigned long long *accepted_total, double proposed, double *out_device,
+                              hipStream_t stream) {
   const int d = nr + 2 * nc;
   const int n_aug = d + nr + nc;
   const int n_entries = 1 + n_aug + d * (d + 1) / 2;
@@ -152,14 +175,14 @@ hipError_t launch_pool_reduce(const void *x, long long n, int nr, int nc, int dt
       if (err != hipSuccess) return err;
     }
     hipLaunchKernelGGL(k_pool_reduce<float>, dim3((unsigned)blocks), dim3(kBlockThreads), lds, stream, (const float *)x, n,
-                       nr, nc, counters, out_device);
+                       nr, nc, accepted_total, proposed, out_device);
   } else {
     if (lds > 64 * 1024) {
       err = hipFuncSetAttribute((const void *)k_pool_reduce<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (err != hipSuccess) return err;
     }
     hipLaunchKernelGGL(k_pool_reduce<double>, dim3((unsigned)blocks), dim3(kBlockThreads), lds, stream, (const double *)x,
-                       n, nr, nc, counters, out_device);
+                       n, nr, nc, accepted_total, proposed, out_device);
   }
   return hipGetLastError();
 }

@@ -31,7 +31,7 @@ struct StepLaunch {
   int n_coef;
   const void *inj_normals;   // non-null: injected streams (f64 kernels only), [sweep][D][n] and [sweep][n]
   const void *inj_uniforms;
-  unsigned long long *counters;  // [0] accepted, [1] proposed
+  unsigned long long *accept_slots;  // per-wavefront accepted counts, [grid_blocks * 4]
   unsigned int *status;
   long long n;
   unsigned long long chain_offset, step_index, seed;
@@ -76,9 +76,21 @@ const KernelSet *find_kernel_set(int dtype, int n_real, int n_complex);
 hipError_t launch_broadcast_rows(void *dst, const void *row_values, int rows, long long n, int dtype,
                                  hipStream_t stream);
 // Ensemble sums (see me_pooled_moments in the public header).  out must hold moments_size doubles and is
-// zeroed by the launcher; counters are appended by the caller.
+// zeroed by the launcher; accepted_total is a device scalar (from launch_sum_slots), proposed is host-known.
 hipError_t launch_pool_reduce(const void *x, long long n, int n_real, int n_complex, int dtype,
-                              const unsigned long long *counters, double *out_device, hipStream_t stream);
+                              const unsigned long long *accepted_total, double proposed, double *out_device,
+                              hipStream_t stream);
+// total[0] = sum of slots[0 .. n_slots)
+hipError_t launch_sum_slots(const unsigned long long *slots, long long n_slots, unsigned long long *total,
+                            hipStream_t stream);
+
+// blocks launched for n chains (one lane per chain, grid-stride beyond `requested` blocks when requested > 0)
+inline int grid_for(long long n, int requested) {
+  long long blocks = (n + kBlockThreads - 1) / kBlockThreads;
+  if (requested > 0 && blocks > requested) blocks = requested;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
 
 __host__ __device__ inline int packed_real(int nr) { return nr * (nr + 1) / 2; }
 __host__ __device__ inline int packed_total(int nr, int nc) { return nr * (nr + 1) / 2 + nc * nc; }

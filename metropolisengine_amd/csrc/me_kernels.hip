@@ -36,13 +36,6 @@ bool has_energy(int kind) {
   }
 }
 
-inline int grid_for(long long n, int requested) {
-  long long blocks = (n + kBlockThreads - 1) / kBlockThreads;
-  if (requested > 0 && blocks > requested) blocks = requested;
-  if (blocks < 1) blocks = 1;
-  return (int)blocks;
-}
-
 template <typename R>
 StepArgs<R> typed(const StepLaunch &l) {
   StepArgs<R> a;
@@ -52,7 +45,7 @@ StepArgs<R> typed(const StepLaunch &l) {
   a.factor = (const R *)l.factor;
   a.inj_normals = (const R *)l.inj_normals;
   a.inj_uniforms = (const R *)l.inj_uniforms;
-  a.counters = l.counters;
+  a.accept_slots = l.accept_slots;
   a.status = l.status;
   a.n = l.n;
   a.chain_offset = l.chain_offset;
