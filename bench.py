@@ -27,6 +27,21 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 
 BYTES_PER_CHAIN_STEP = 8 * N_REAL + 16   # fp32 r/w of x[16], energy, width: SURVEY.md 8(d), B_step(identity) = 144 B
 
 
+def pmc_traffic(chains_log2, sweeps):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r*_pmc_traffic.json): FETCH_SIZE
+    (x2, gfx950 correction) + WRITE_SIZE, separate passes.  PMC collection cannot run inside the timed bench, so
+    the figure is taken from the newest committed pass of this same workload; None for any other workload."""
+    if chains_log2 != 20 or sweeps != 1:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        rec = json.load(fh)
+    return rec.get("traffic_bytes_per_launch")
+
+
 def cpu_baseline(seconds):
     """Python restatement of the reference loop, one chain per process on the host cores (no GPU involved)."""
     cores = max(1, min(os.cpu_count() or 1, 16))
@@ -135,7 +150,7 @@ def main():
                        "chains_per_gpu": n_local, "global_chains": n_local * world, "sweeps_per_launch": args.sweeps,
                        "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.chains_log2, args.sweeps),
                          "kernel": "k_step<float,16,0,EnergyIso,identity>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algorithmic,
                          "note": "144 B per chain-step (fp32 r/w of x[16], energy, width) x 2^%d chains / average "
