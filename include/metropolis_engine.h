@@ -58,7 +58,10 @@ typedef enum me_energy_kind {
   ME_ENERGY_DIAG_QUAD = 1,  /* coeffs {a_0..a_{nr-1}, b_0..b_{nc-1}}: sum a x^2 + sum b |z|^2 */
   ME_ENERGY_DENSE_QUAD = 2, /* coeffs A[D*D] row-major: x^T A x over the real D-vector */
   ME_ENERGY_LANDAU_TOY = 3, /* coeffs {k, alpha, beta}, nr=2, nc=1   demo/toymodel_complex_and_real.py:17-26 */
-  ME_ENERGY_CYLINDER = 4    /* coeffs {kappa, gamma, wavenumber}: cylinder-style surrogate */
+  ME_ENERGY_CYLINDER = 4,   /* coeffs {kappa, gamma, wavenumber}: cylinder-style surrogate */
+  ME_ENERGY_USER = 5,       /* user-written device function from a plugin (include/metropolis_user_energy.h),
+                               inlined into the kernels; coeffs are handed to it in device memory */
+  ME_ENERGY_USER_INDIRECT = 6 /* the same function called through a __device__ function pointer */
 } me_energy_kind;
 
 /* Hard-wall predicate evaluated before the energy (metropolis_engine.py:142-146, :247-249). */
@@ -109,9 +112,14 @@ typedef struct me_config {
   const double *initial_params;     /* [D], broadcast to every chain */
   const double *covariance_real;    /* [nr*nr] row-major or NULL = identity (metropolis_engine.py:63-66) */
   const double *covariance_complex; /* [nc*nc*2] row-major (Re,Im) or NULL = identity (:67-70) */
+  const char *user_energy_name;     /* ME_ENERGY_USER*: name the plugin was built with (NULL otherwise) */
 } me_config;
 
 int me_abi_version(void);
+
+/* Load a user-energy plugin library (built from the user's device function around the same kernels; it registers
+ * itself).  The reference's counterpart is simply passing a Python callable (metropolis_engine.py:20). */
+int me_load_plugin(const char *path);
 
 int me_create(const me_config *config, me_engine **out);
 int me_destroy(me_engine *engine);

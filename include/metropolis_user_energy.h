@@ -1,0 +1,28 @@
+/*
+ * metropolis_user_energy.h -- contract for a user-written device energy (me_energy_kind ME_ENERGY_USER /
+ * ME_ENERGY_USER_INDIRECT).
+ *
+ * The reference couples the sampler to the physics through a Python callable
+ *     energy(real_params, complex_params) -> float            (metropolisengine/metropolis_engine.py:20, :250)
+ * The GPU counterpart is one HIP source file that defines
+ *
+ *     template <typename R>
+ *     __device__ R me_user_energy(const R *x, const R *coef);
+ *
+ * where x[ME_NR + 2*ME_NC] is the chain's state [real params | Re z | Im z] (ME_NR / ME_NC are compile-time macros
+ * equal to n_real / n_complex) and coef points to the engine's energy coefficients in device memory (the doubles
+ * passed as me_config.energy_coeffs, converted to R; NULL if there are none).  The function must be pure and must
+ * not synchronise.  It is compiled around the engine's own kernels into a plugin library:
+ *
+ *     python -c "from metropolisengine_amd import build; build.build_user_energy('my_energy.h', 'mine', 2, 7)"
+ *     -> metropolisengine_amd/lib/libme_user_mine_2_7.so
+ *
+ * which registers itself when loaded with me_load_plugin(path); engines select it with
+ * me_config.energy_kind = ME_ENERGY_USER (inlined call) or ME_ENERGY_USER_INDIRECT (call through a __device__
+ * function pointer held in the plugin's code object) and me_config.user_energy_name = "mine".
+ * A hard-wall predicate stays in me_config.reject_kind (evaluated before the energy, metropolis_engine.py:247).
+ */
+#ifndef METROPOLIS_USER_ENERGY_H
+#define METROPOLIS_USER_ENERGY_H
+#include <hip/hip_runtime.h>
+#endif

@@ -11,7 +11,8 @@ ABI_VERSION = 1
 
 ME_OK, ME_ERR_INVALID, ME_ERR_UNSUPPORTED, ME_ERR_HIP, ME_ERR_NUMERIC, ME_ERR_STATE = range(6)
 ME_F32, ME_F64 = 0, 1
-(ENERGY_ISO_QUAD, ENERGY_DIAG_QUAD, ENERGY_DENSE_QUAD, ENERGY_LANDAU_TOY, ENERGY_CYLINDER) = range(5)
+(ENERGY_ISO_QUAD, ENERGY_DIAG_QUAD, ENERGY_DENSE_QUAD, ENERGY_LANDAU_TOY, ENERGY_CYLINDER, ENERGY_USER,
+ ENERGY_USER_INDIRECT) = range(7)
 REJECT_NONE, REJECT_ABS_REAL0_GE = 0, 1
 COV_REFERENCE, COV_FIXED, COV_POOLED = 0, 1, 2
 (FIELD_PARAMS, FIELD_ENERGY, FIELD_WIDTH, FIELD_MEAN, FIELD_COV, FIELD_OBS_MEAN, FIELD_FACTOR) = range(7)
@@ -30,6 +31,7 @@ class MeConfig(ctypes.Structure):
         ("energy_kind", ctypes.c_int32), ("n_energy_coeffs", ctypes.c_int32), ("energy_coeffs", _dp),
         ("reject_kind", ctypes.c_int32), ("reserved0", ctypes.c_int32), ("reject_bound", ctypes.c_double),
         ("initial_params", _dp), ("covariance_real", _dp), ("covariance_complex", _dp),
+        ("user_energy_name", ctypes.c_char_p),
     ]
 
 
@@ -37,6 +39,7 @@ class MeConfig(ctypes.Structure):
 _H = ctypes.c_void_p
 SYMBOLS = {
     "me_abi_version": (ctypes.c_int, []),
+    "me_load_plugin": (ctypes.c_int, [ctypes.c_char_p]),
     "me_create": (ctypes.c_int, [ctypes.POINTER(MeConfig), ctypes.POINTER(_H)]),
     "me_destroy": (ctypes.c_int, [_H]),
     "me_step": (ctypes.c_int, [_H, ctypes.c_int32]),
@@ -83,7 +86,7 @@ def load():
             "libmetropolis_hip.so not found at %s: build it with `python -m metropolisengine_amd.build` "
             "(needs hipcc). metropolisengine_amd has no CPU fallback." % LIB_PATH)
     try:
-        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_LOCAL)
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)   # plugins resolve me::register_kernel_set against it
     except OSError as exc:
         raise MetropolisLibraryError("could not load %s: %s" % (LIB_PATH, exc)) from exc
     for name, (restype, argtypes) in SYMBOLS.items():

@@ -87,6 +87,40 @@ def build(force=False, jobs=None, verbose=True, extra_flags=()):
     return LIB_PATH
 
 
+def user_plugin_path(name, n_real, n_complex):
+    return os.path.join(LIB_DIR, "libme_user_%s_%d_%d.so" % (name, n_real, n_complex))
+
+
+def build_user_energy(source, name, n_real, n_complex, force=False, per_chain=True):
+    """Compile a user device energy (include/metropolis_user_energy.h) around the engine's kernels into a plugin.
+
+    Returns the plugin path (``lib/libme_user_<name>_<nr>_<nc>.so``); load it with ``me_load_plugin``.
+    """
+    source = os.path.abspath(source)
+    if not name.isidentifier():
+        raise ValueError("plugin name must be an identifier")
+    build(verbose=False)                      # the plugin links against libmetropolis_hip.so
+    out = user_plugin_path(name, n_real, n_complex)
+    deps = [source, os.path.join(CSRC, "me_kernels.hip"), LIB_PATH] + \
+           [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    if not force and _newer(out, deps):
+        return out
+    inc = os.path.join(os.path.dirname(PKG_DIR), "include")
+    _run([hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-I", inc,
+          "-I", os.path.dirname(source),
+          "-DME_NR=%d" % n_real, "-DME_NC=%d" % n_complex, "-DME_PER_CHAIN=%d" % int(per_chain),
+          "-DME_USER_SOURCE=\"%s\"" % source, "-DME_USER_NAME=\"%s\"" % name,
+          os.path.join(CSRC, "me_kernels.hip"), "-o", out,
+          "-L", LIB_DIR, "-lmetropolis_hip", "-Wl,-rpath,$ORIGIN"])
+    return out
+
+
+def build_examples(force=False):
+    """The shipped example plugin: cylinder-style surrogate for BASELINE config 5 (2 real + 7 complex)."""
+    src = os.path.join(os.path.dirname(PKG_DIR), "examples", "user_energy_cylinder.h")
+    return [build_user_energy(src, "cylinder", 2, 7, force=force)]
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
@@ -94,6 +128,7 @@ if __name__ == "__main__":
     args = ap.parse_args()
     try:
         build(force=args.force, jobs=args.jobs)
+        build_examples(force=args.force)
     except RuntimeError as exc:
         print(exc, file=sys.stderr)
         sys.exit(1)

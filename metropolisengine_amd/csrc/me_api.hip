@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -19,10 +20,21 @@ static std::vector<const KernelSet *> &registry() {
   return sets;
 }
 void register_kernel_set(const KernelSet *set) { registry().push_back(set); }
-const KernelSet *find_kernel_set(int dtype, int n_real, int n_complex) {
-  for (const KernelSet *s : registry())
-    if (s->dtype == dtype && s->n_real == n_real && s->n_complex == n_complex) return s;
+static bool is_user_kind(int kind) { return kind == ME_ENERGY_USER || kind == ME_ENERGY_USER_INDIRECT; }
+const KernelSet *find_kernel_set(int dtype, int n_real, int n_complex, int energy_kind, const char *user_name) {
+  for (const KernelSet *s : registry()) {
+    if (s->dtype != dtype || s->n_real != n_real || s->n_complex != n_complex || !s->has_energy(energy_kind)) continue;
+    if (is_user_kind(energy_kind)) {
+      if (!s->user_name || !user_name || std::strcmp(s->user_name, user_name) != 0) continue;
+    }
+    return s;
+  }
   return nullptr;
+}
+bool has_dims(int dtype, int n_real, int n_complex) {
+  for (const KernelSet *s : registry())
+    if (s->dtype == dtype && s->n_real == n_real && s->n_complex == n_complex && !s->user_name) return true;
+  return false;
 }
 
 // ------------------------------------------------------------------------------------------------ helpers
@@ -228,8 +240,7 @@ extern "C" {
 int me_abi_version(void) { return ME_ABI_VERSION; }
 
 int me_supported(int32_t dtype, int32_t n_real, int32_t n_complex, int32_t energy_kind) {
-  const KernelSet *ks = find_kernel_set(dtype, n_real, n_complex);
-  return ks && ks->has_energy(energy_kind) ? 1 : 0;
+  return find_kernel_set(dtype, n_real, n_complex, energy_kind, nullptr) ? 1 : 0;
 }
 
 int me_create(const me_config *c, me_engine **out) {
@@ -250,14 +261,20 @@ int me_create(const me_config *c, me_engine **out) {
     return fail(nullptr, ME_ERR_INVALID, "energy coefficients missing");
   if (c->cov_mode < ME_COV_REFERENCE || c->cov_mode > ME_COV_POOLED)
     return fail(nullptr, ME_ERR_INVALID, "unknown cov_mode");
-  const KernelSet *ks = find_kernel_set(c->dtype, c->n_real, c->n_complex);
-  if (!ks)
-    return fail(nullptr, ME_ERR_UNSUPPORTED,
-                "no kernel set compiled for (dtype, n_real, n_complex) = (" + std::to_string(c->dtype) + ", " +
-                    std::to_string(c->n_real) + ", " + std::to_string(c->n_complex) + ")");
-  if (!ks->has_energy(c->energy_kind))
+  const KernelSet *ks = find_kernel_set(c->dtype, c->n_real, c->n_complex, c->energy_kind, c->user_energy_name);
+  if (!ks) {
+    if (is_user_kind(c->energy_kind))
+      return fail(nullptr, ME_ERR_UNSUPPORTED,
+                  std::string("no user-energy plugin named '") + (c->user_energy_name ? c->user_energy_name : "") +
+                      "' is loaded for these dimensions (build it with metropolisengine_amd.build.build_user_energy "
+                      "and load it with me_load_plugin)");
+    if (!has_dims(c->dtype, c->n_real, c->n_complex))
+      return fail(nullptr, ME_ERR_UNSUPPORTED,
+                  "no kernel set compiled for (dtype, n_real, n_complex) = (" + std::to_string(c->dtype) + ", " +
+                      std::to_string(c->n_real) + ", " + std::to_string(c->n_complex) + ")");
     return fail(nullptr, ME_ERR_UNSUPPORTED, "energy kind " + std::to_string(c->energy_kind) +
                                                   " is not compiled for these dimensions");
+  }
   if (c->cov_mode == ME_COV_REFERENCE && !ks->per_chain_cov)
     return fail(nullptr, ME_ERR_UNSUPPORTED,
                 "per-chain adaptive covariance is not compiled for these dimensions; use ME_COV_FIXED or ME_COV_POOLED");
@@ -326,7 +343,7 @@ int me_create(const me_config *c, me_engine **out) {
   ME_CREATE_HIP(hipMalloc((void **)&e->pool_dev, sizeof(double) * (size_t)moments_size(e->nr, e->nc)));
   ME_CREATE_HIP(hipMemsetAsync(e->accept_slots, 0, (size_t)e->n_slots * sizeof(unsigned long long), e->stream));
   ME_CREATE_HIP(hipMemsetAsync(e->status, 0, sizeof(unsigned int), e->stream));
-  if (e->energy_kind == ME_ENERGY_DENSE_QUAD) {
+  if (e->energy_kind == ME_ENERGY_DENSE_QUAD || (is_user_kind(e->energy_kind) && !e->coef.empty())) {
     std::vector<unsigned char> bytes;
     to_device_type(e->coef.data(), e->coef.size(), e->dtype, bytes);
     ME_CREATE_HIP(hipMalloc(&e->coef_dev, bytes.size()));
@@ -401,6 +418,14 @@ int me_create(const me_config *c, me_engine **out) {
     return rc;
   }
   *out = e;
+  return ME_OK;
+}
+
+int me_load_plugin(const char *path) {
+  if (!path) return fail(nullptr, ME_ERR_INVALID, "null plugin path");
+  // the plugin's static initialiser registers its kernel sets (me::register_kernel_set)
+  void *handle = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+  if (!handle) return fail(nullptr, ME_ERR_INVALID, std::string("dlopen failed: ") + dlerror());
   return ME_OK;
 }
 

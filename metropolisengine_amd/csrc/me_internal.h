@@ -60,6 +60,7 @@ struct EnergyLaunch {
 };
 
 struct KernelSet {
+  const char *user_name;  // nullptr for the built-in sets; the plugin's name for user-energy sets
   int dtype, n_real, n_complex;
   bool per_chain_cov;  // measure can refresh per-chain factors / step can read them
   bool (*has_energy)(int energy_kind);
@@ -69,7 +70,9 @@ struct KernelSet {
 };
 
 void register_kernel_set(const KernelSet *set);
-const KernelSet *find_kernel_set(int dtype, int n_real, int n_complex);
+// first registered set for these dimensions that implements `energy_kind` (user kinds: with this plugin name)
+const KernelSet *find_kernel_set(int dtype, int n_real, int n_complex, int energy_kind, const char *user_name);
+bool has_dims(int dtype, int n_real, int n_complex);
 
 // ---- dimension-independent kernels (me_generic.hip) -------------------------------------------------------
 // dst[r*n + c] = row_values[r] for r < rows, c < n   (broadcast one chain's vector to all chains)

@@ -6,6 +6,12 @@
 
 #include "me_device.h"
 
+// User-energy plugin mode: -DME_USER_SOURCE='"file"' -DME_USER_NAME='"name"' compiles the SAME kernels around a
+// user-written device function (include/metropolis_user_energy.h) into a plugin library that registers itself.
+#ifdef ME_USER_SOURCE
+#include ME_USER_SOURCE
+#endif
+
 #ifndef ME_NR
 #error "compile with -DME_NR=<n_real> -DME_NC=<n_complex>"
 #endif
@@ -25,7 +31,42 @@ constexpr int NC = ME_NC;
 constexpr bool kLandau = (NR == 2 && NC == 1);
 constexpr bool kCylinder = (NR >= 1 && NC >= 1);
 
+#ifdef ME_USER_SOURCE
+// Direct form: the user function is inlined into k_step (state stays in registers).
+template <typename R, int NR_, int NC_>
+struct EnergyUser {
+  static constexpr int D = NR_ + 2 * NC_;
+  const R *coef;
+  __device__ __forceinline__ R operator()(const R (&x)[D]) const { return me_user_energy<R>(x, coef); }
+};
+// Indirect form: the call goes through a __device__ function pointer read from the plugin's code object
+// (BASELINE config 5: "user-callback energy via device fn pointer"); costs a real call and a private-memory x.
+template <typename R>
+using user_fn_t = R (*)(const R *, const R *);
+template <typename R>
+__device__ R me_user_energy_entry(const R *x, const R *coef) { return me_user_energy<R>(x, coef); }
+__device__ user_fn_t<float> g_user_fn_f32 = &me_user_energy_entry<float>;
+__device__ user_fn_t<double> g_user_fn_f64 = &me_user_energy_entry<double>;
+template <typename R, int NR_, int NC_>
+struct EnergyUserIndirect {
+  static constexpr int D = NR_ + 2 * NC_;
+  user_fn_t<R> fn;
+  const R *coef;
+  __device__ __forceinline__ R operator()(const R (&x)[D]) const { return fn(x, coef); }
+};
+template <typename R>
+user_fn_t<R> load_user_fn() {
+  user_fn_t<R> fn = nullptr;
+  if constexpr (std::is_same<R, float>::value) (void)hipMemcpyFromSymbol(&fn, HIP_SYMBOL(g_user_fn_f32), sizeof(fn));
+  else (void)hipMemcpyFromSymbol(&fn, HIP_SYMBOL(g_user_fn_f64), sizeof(fn));
+  return fn;
+}
+#endif
+
 bool has_energy(int kind) {
+#ifdef ME_USER_SOURCE
+  return kind == ME_ENERGY_USER || kind == ME_ENERGY_USER_INDIRECT;
+#endif
   switch (kind) {
     case ME_ENERGY_ISO_QUAD:
     case ME_ENERGY_DIAG_QUAD: return true;
@@ -99,6 +140,19 @@ hipError_t step_with(const StepLaunch &l, const Energy &en, hipStream_t stream) 
 // Build the by-value energy functor from the coefficient list and hand it to `f`.
 template <typename R, class F>
 hipError_t with_energy(int kind, const double *coef, int n_coef, const void *coef_device, F &&f) {
+#ifdef ME_USER_SOURCE
+  if (kind == ME_ENERGY_USER) {
+    EnergyUser<R, NR, NC> en{(const R *)coef_device};
+    return f(en);
+  }
+  if (kind == ME_ENERGY_USER_INDIRECT) {
+    static const user_fn_t<R> fn = load_user_fn<R>();
+    if (!fn) return hipErrorInvalidDeviceFunction;
+    EnergyUserIndirect<R, NR, NC> en{fn, (const R *)coef_device};
+    return f(en);
+  }
+  return hipErrorInvalidValue;
+#else
   switch (kind) {
     case ME_ENERGY_ISO_QUAD: {
       if (n_coef != 1) return hipErrorInvalidValue;
@@ -137,6 +191,7 @@ hipError_t with_energy(int kind, const double *coef, int n_coef, const void *coe
     }
     default: return hipErrorInvalidValue;
   }
+#endif
 }
 
 template <typename R>
@@ -177,8 +232,13 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
   return hipGetLastError();
 }
 
-const KernelSet kSetF32 = {ME_F32, NR, NC, ME_PER_CHAIN != 0, has_energy, step<float>, measure<float>, init_energy<float>};
-const KernelSet kSetF64 = {ME_F64, NR, NC, ME_PER_CHAIN != 0, has_energy, step<double>, measure<double>,
+#ifdef ME_USER_SOURCE
+#define ME_SET_NAME ME_USER_NAME
+#else
+#define ME_SET_NAME nullptr
+#endif
+const KernelSet kSetF32 = {ME_SET_NAME, ME_F32, NR, NC, ME_PER_CHAIN != 0, has_energy, step<float>, measure<float>, init_energy<float>};
+const KernelSet kSetF64 = {ME_SET_NAME, ME_F64, NR, NC, ME_PER_CHAIN != 0, has_energy, step<double>, measure<double>,
                            init_energy<double>};
 
 struct Registrar {

@@ -85,6 +85,41 @@ class CylinderSurrogate(EnergySpec):
         return np.array([self.kappa, self.gamma, self.wavenumber], dtype=np.float64)
 
 
+class UserEnergy(EnergySpec):
+    """A user-written device function (include/metropolis_user_energy.h) -- the GPU form of the reference's
+    ``energy(real_params, complex_params)`` callback (metropolis_engine.py:20).
+
+    ``source`` is the HIP header defining ``me_user_energy``; it is compiled (hipcc, once per name and dimensions)
+    around the engine's kernels into ``lib/libme_user_<name>_<nr>_<nc>.so`` and loaded with ``me_load_plugin``.
+    ``indirect=True`` calls it through a ``__device__`` function pointer instead of inlining it.
+    """
+
+    def __init__(self, name, source=None, coefficients=(), indirect=False):
+        self.name = name
+        self.source = source
+        self.coeffs = np.asarray(coefficients, dtype=np.float64).ravel()
+        self.kind = _capi.ENERGY_USER_INDIRECT if indirect else _capi.ENERGY_USER
+        self._loaded = set()
+
+    def coefficients(self, n_real, n_complex):
+        return self.coeffs
+
+    def ensure_loaded(self, n_real, n_complex):
+        """Build (if a source is given and the plugin is stale) and load the plugin for these dimensions."""
+        import os
+        from . import build
+        key = (n_real, n_complex)
+        if key in self._loaded:
+            return
+        path = build.user_plugin_path(self.name, n_real, n_complex)
+        if self.source is not None:
+            path = build.build_user_energy(self.source, self.name, n_real, n_complex)
+        elif not os.path.exists(path):
+            raise _capi.MetropolisLibraryError("user-energy plugin %s not found and no source given" % path)
+        _capi.check(_capi.load().me_load_plugin(path.encode()))
+        self._loaded.add(key)
+
+
 class RejectSpec:
     kind = _capi.REJECT_NONE
     bound = 0.0

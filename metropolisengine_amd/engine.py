@@ -137,6 +137,10 @@ class MetropolisEngine:
         cfg.target_acceptance = float(target_acceptance)
         cfg.sampling_width = float(sampling_width)
         cfg.energy_kind = energy_functions.kind
+        if hasattr(energy_functions, "ensure_loaded"):          # UserEnergy: build + load its plugin library
+            energy_functions.ensure_loaded(nr, nc)
+            self._user_name = energy_functions.name.encode()
+            cfg.user_energy_name = self._user_name
         cfg.n_energy_coeffs = int(coeffs.size)
         cfg.energy_coeffs = _as_double_ptr(coeffs)
         cfg.reject_kind = reject_condition.kind if reject_condition is not None else _capi.REJECT_NONE

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_config_struct_layout_matches_header():
     # natural C layout of struct me_config on x86-64
-    assert ctypes.sizeof(_capi.MeConfig) == 128
+    assert ctypes.sizeof(_capi.MeConfig) == 136
     assert _capi.MeConfig.n_chains.offset == 8 and _capi.MeConfig.temp.offset == 48
     assert _capi.MeConfig.energy_coeffs.offset == 80 and _capi.MeConfig.covariance_complex.offset == 120
 
@@ -92,3 +92,29 @@ def test_packed_layout_helpers():
     cplx = unpack_complex_block(packed, nr, nc)[0]
     assert cplx[0, 0] == packed[0, pr] and cplx[1, 0] == packed[0, pr + 1] + 1j * packed[0, pr + 2]
     assert cplx[0, 1] == np.conj(cplx[1, 0]) and cplx[1, 1] == packed[0, pr + 3]
+
+
+def test_user_energy_plugin_loads_and_registers():
+    """The example plugin (examples/user_energy_cylinder.h compiled around the kernels) resolves against the main
+    library and registers its kernel sets; a missing path fails loudly."""
+    from metropolisengine_amd import build
+    lib = _capi.load()
+    path = build.user_plugin_path("cylinder", 2, 7)
+    assert os.path.exists(path), "run `python -m metropolisengine_amd.build` (it builds the example plugin)"
+    assert lib.me_load_plugin(path.encode()) == _capi.ME_OK
+    assert lib.me_load_plugin(b"/nonexistent/libme_user_x.so") == _capi.ME_ERR_INVALID
+    assert "dlopen" in _capi.last_error()
+    # an engine asking for an unknown plugin name is refused before any device work
+    cfg = _capi.MeConfig()
+    init, coef = np.zeros(16), np.ones(3)
+    cfg.abi_version, cfg.n_chains, cfg.n_real, cfg.n_complex = _capi.ABI_VERSION, 8, 2, 7
+    cfg.target_acceptance, cfg.sampling_width, cfg.temp = 0.3, 0.05, 0.1
+    cfg.energy_kind, cfg.n_energy_coeffs = _capi.ENERGY_USER, 3
+    cfg.energy_coeffs = coef.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    cfg.initial_params = init.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    cfg.user_energy_name = b"no_such_plugin"
+    handle = ctypes.c_void_p()
+    assert lib.me_create(ctypes.byref(cfg), ctypes.byref(handle)) == _capi.ME_ERR_UNSUPPORTED
+    assert "no_such_plugin" in _capi.last_error()
+    cfg.user_energy_name = b"cylinder"
+    assert lib.me_create(ctypes.byref(cfg), ctypes.byref(handle)) == _capi.ME_ERR_HIP   # found; no GPU here

@@ -324,3 +324,48 @@ def test_full_size_properties_config2():
     assert st["n_chains"] == n
     assert np.all(np.abs(np.diag(st["covariance"]) - 0.5) < 6 * 0.5 * np.sqrt(2.0 / n) + 2e-3)
     assert 0.2 < st["acceptance_rate"] < 0.45
+
+
+def test_user_energy_plugin_matches_builtin_and_oracle():
+    """BASELINE config 5 shape (2 real + 7 complex, hard wall |x0| >= 1): the user-callback plugin
+    (examples/user_energy_cylinder.h), inlined and through a __device__ function pointer, against the built-in
+    surrogate (bitwise, float32) and the oracle (float64, 1e-9)."""
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "user_energy_cylinder.h")
+    coef = (1.0, 0.5, 1.0)
+    real0, cplx0 = [0.1, 0.0], [0.05] * 7
+    common = dict(temp=0.1, n_chains=2048, seed=2026)
+    wall = me.AbsReal0AtLeast(1.0)
+    builtin = me.MetropolisEngine(me.CylinderSurrogate(*coef), wall, real0, cplx0, **common)
+    direct = me.MetropolisEngine(me.UserEnergy("cylinder", src, coef), wall, real0, cplx0, **common)
+    indirect = me.MetropolisEngine(me.UserEnergy("cylinder", src, coef, indirect=True), wall, real0, cplx0, **common)
+    # short horizon: the three code paths take the same decisions (float32 rounding may differ in the last bit)
+    for eng in (builtin, direct, indirect):
+        eng.step_all(3)
+    for field in (0, 1, 2):
+        ref = builtin._get(field)
+        assert np.allclose(direct._get(field), ref, rtol=1e-5, atol=1e-6), field
+        assert np.allclose(indirect._get(field), ref, rtol=1e-5, atol=1e-6), field
+    # long horizon: float32 trajectories may diverge after a rounding-level accept flip, the statistics may not
+    for eng in (builtin, direct, indirect):
+        for _ in range(60):
+            eng.step_all(10)
+            eng.measure()
+    from metropolisengine_amd.distributed import moments_to_statistics
+    stats = [moments_to_statistics(eng.pooled_moments(), 2, 7) for eng in (builtin, direct, indirect)]
+    for st in stats[1:]:
+        assert abs(st["acceptance_rate"] - stats[0]["acceptance_rate"]) < 0.01
+        assert np.allclose(np.diag(st["covariance"]), np.diag(stats[0]["covariance"]), rtol=0.15)
+    assert np.all(np.abs(builtin._get(0)[:, 0]) < 1.0) and np.all(np.abs(indirect._get(0)[:, 0]) < 1.0)   # the wall
+    # float64 plugin vs the oracle on the same Philox streams
+    eng = me.MetropolisEngine(me.UserEnergy("cylinder", src, coef), wall, real0, cplx0, temp=0.1, n_chains=128,
+                              seed=5, dtype="f64")
+    ora = ManyChainOracle(2, 7, energies.cylinder_surrogate(2, 7, *coef), 128, seed=5, temp=0.1,
+                          initial_real_params=real0, initial_complex_params=cplx0, reject=energies.wall_reject(1.0))
+    for _ in range(55):
+        eng.step_all(4)
+        ora.step(4)
+        eng.measure()
+        ora.measure()
+    assert np.allclose(eng._get(0), ora.x, rtol=0, atol=TOL)
+    assert np.allclose(eng.covariance_matrix_complex, ora.cov_complex, rtol=0, atol=TOL)
+    assert eng.accept_stats() == (ora.accepted, ora.proposed)
