@@ -6,7 +6,7 @@ import ctypes
 import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "lib", "libmetropolis_hip.so")
+LIB_PATH = os.environ.get("METROPOLIS_HIP_LIB") or os.path.join(PKG_DIR, "lib", "libmetropolis_hip.so")
 ABI_VERSION = 1
 
 ME_OK, ME_ERR_INVALID, ME_ERR_UNSUPPORTED, ME_ERR_HIP, ME_ERR_NUMERIC, ME_ERR_STATE = range(6)

@@ -118,7 +118,7 @@ struct me_engine {
   unsigned long long step_index = 0, measure_count = 1;   // counters start at 1 (metropolis_engine.py:72-75)
   // device buffers (SoA: component-major, chain-minor)
   void *x = nullptr, *energy = nullptr, *width = nullptr, *mean = nullptr, *cov = nullptr, *obs_mean = nullptr;
-  void *factor = nullptr, *shared_factor = nullptr, *coef_dev = nullptr, *row_dev = nullptr;
+  void *factor = nullptr, *shared_factor = nullptr, *shared_full = nullptr, *coef_dev = nullptr, *row_dev = nullptr;
   unsigned long long *accept_slots = nullptr, *accept_total = nullptr;
   long long n_slots = 0;
   unsigned long long proposed = 0;
@@ -193,11 +193,28 @@ int check_status(me_engine *e) {
   return fail(e, ME_ERR_NUMERIC, msg);
 }
 
+// Upload the shared proposal factor: packed (ME_FIELD_FACTOR layout) and, for pure-real engines, also as a dense
+// row-major [nr][nr] lower-triangular matrix (operand of the matrix-core proposal kernel).
+int upload_shared_factor(me_engine *e, const double *packed) {
+  std::vector<unsigned char> bytes;
+  to_device_type(packed, (size_t)e->p, e->dtype, bytes);
+  ME_HIP(e, hipMemcpy(e->shared_factor, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+  if (e->shared_full) {
+    std::vector<double> full((size_t)e->nr * e->nr, 0.0);
+    for (int i = 0; i < e->nr; ++i)
+      for (int j = 0; j <= i; ++j) full[(size_t)i * e->nr + j] = packed[i * (i + 1) / 2 + j];
+    to_device_type(full.data(), full.size(), e->dtype, bytes);
+    ME_HIP(e, hipMemcpy(e->shared_full, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+  }
+  return ME_OK;
+}
+
 void fill_step_launch(me_engine *e, StepLaunch &l, int n_sweeps) {
   l.x = e->x;
   l.energy = e->energy;
   l.width = e->width;
   l.factor = e->cov_kind == CK_PER_CHAIN ? e->factor : e->shared_factor;
+  l.factor_full = e->shared_full;
   l.coef_device = e->coef_dev;
   l.coef_host = e->coef.data();
   l.n_coef = (int)e->coef.size();
@@ -225,7 +242,7 @@ void fill_step_launch(me_engine *e, StepLaunch &l, int n_sweeps) {
 void release(me_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  void *bufs[] = {e->x, e->energy, e->width, e->mean, e->cov, e->obs_mean, e->factor, e->shared_factor,
+  void *bufs[] = {e->x, e->energy, e->width, e->mean, e->cov, e->obs_mean, e->factor, e->shared_factor, e->shared_full,
                   e->coef_dev, e->row_dev, e->accept_slots, e->accept_total, e->status, e->pool_dev};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -335,6 +352,7 @@ int me_create(const me_config *c, me_engine **out) {
     ME_CREATE_HIP(hipMalloc(&e->factor, n * e->p * es));
   }
   ME_CREATE_HIP(hipMalloc(&e->shared_factor, (size_t)e->p * es));
+  if (e->nc == 0) ME_CREATE_HIP(hipMalloc(&e->shared_full, (size_t)e->nr * e->nr * es));
   ME_CREATE_HIP(hipMalloc(&e->row_dev, (size_t)std::max(std::max(e->d, e->p), e->nobs) * es));
   e->n_slots = (long long)grid_for(e->n, e->grid_blocks) * (kBlockThreads / 64);
   ME_CREATE_HIP(hipMalloc((void **)&e->accept_slots, (size_t)e->n_slots * sizeof(unsigned long long)));
@@ -397,13 +415,10 @@ int me_create(const me_config *c, me_engine **out) {
     release(e);
     return rc;
   }
-  {
-    std::vector<unsigned char> bytes;
-    to_device_type(f0.data(), f0.size(), e->dtype, bytes);
-    if (hipMemcpy(e->shared_factor, bytes.data(), bytes.size(), hipMemcpyHostToDevice) != hipSuccess) {
-      release(e);
-      return fail(nullptr, ME_ERR_HIP, "upload of the initial proposal factor failed");
-    }
+  if (upload_shared_factor(e, f0.data()) != ME_OK) {
+    g_create_error = e->err;
+    release(e);
+    return ME_ERR_HIP;
   }
   e->cov_kind = identity ? CK_IDENTITY : CK_SHARED;
 
@@ -662,10 +677,9 @@ int me_set_shared_factor(me_engine *e, const double *packed_factor, int64_t n_do
   if (e->cov_mode != ME_COV_POOLED) return fail(e, ME_ERR_STATE, "me_set_shared_factor needs cov_mode = ME_COV_POOLED");
   if (n_doubles != e->p) return fail(e, ME_ERR_INVALID, "wrong packed factor length");
   ME_HIP(e, hipSetDevice(e->device));
-  std::vector<unsigned char> bytes;
-  to_device_type(packed_factor, (size_t)n_doubles, e->dtype, bytes);
   ME_HIP(e, hipStreamSynchronize(e->stream));
-  ME_HIP(e, hipMemcpy(e->shared_factor, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+  int rc = upload_shared_factor(e, packed_factor);
+  if (rc != ME_OK) return rc;
   e->cov_kind = CK_SHARED;
   return ME_OK;
 }

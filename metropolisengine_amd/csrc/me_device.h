@@ -200,8 +200,39 @@ __host__ __device__ constexpr int cdiag(int pr, int i) { return pr + i * i + 2 *
 
 // INJECT = true replaces the Philox draws by caller-provided streams (test hook: replays the reference's golden
 // trajectories, tests/golden/, through the very same proposal / accept / adapt code).
+// Tuning knobs (experiments; defaults are the shipped configuration):
+//   ME_STEP_WAVES_PER_EU  second __launch_bounds__ argument (min waves per SIMD -> VGPR budget); 0 = unset
+//   ME_STEP_NT            1 = non-temporal state loads, 2 = non-temporal state stores, 3 = both
+#ifndef ME_STEP_WAVES_PER_EU
+#define ME_STEP_WAVES_PER_EU 0
+#endif
+#ifndef ME_STEP_NT
+#define ME_STEP_NT 0
+#endif
+#if ME_STEP_WAVES_PER_EU > 0
+#define ME_STEP_BOUNDS __launch_bounds__(kBlockThreads, ME_STEP_WAVES_PER_EU)
+#else
+#define ME_STEP_BOUNDS __launch_bounds__(kBlockThreads)
+#endif
+template <typename T>
+__device__ __forceinline__ T state_load(const T *p) {
+#if ME_STEP_NT & 1
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void state_store(T *p, T v) {
+#if ME_STEP_NT & 2
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 template <typename R, int NR, int NC, class Energy, int CK, bool INJECT = false>
-__global__ void __launch_bounds__(kBlockThreads) k_step(StepArgs<R> a, Energy en) {
+__global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   constexpr int D = NR + 2 * NC;
   constexpr int PR = NR * (NR + 1) / 2;
   constexpr int NW = 2 * ((D + 1) / 2);     // words consumed by the Box-Muller pairs
@@ -214,9 +245,9 @@ __global__ void __launch_bounds__(kBlockThreads) k_step(StepArgs<R> a, Energy en
   for (long long c = (long long)blockIdx.x * kBlockThreads + threadIdx.x; c < a.n; c += stride) {
     R x[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) x[d] = a.x[(long long)d * a.n + c];
-    R e = a.energy[c];
-    R w = a.width[c];
+    for (int d = 0; d < D; ++d) x[d] = state_load(&a.x[(long long)d * a.n + c]);
+    R e = state_load(&a.energy[c]);
+    R w = state_load(&a.width[c]);
     const unsigned long long gid = a.chain_offset + (unsigned long long)c;
     // CK_PER_CHAIN reads element k at factor[k*n + c] (coalesced); CK_SHARED reads factor[k] (wave-uniform)
     auto fac = [&](int k) -> R {
@@ -307,9 +338,9 @@ __global__ void __launch_bounds__(kBlockThreads) k_step(StepArgs<R> a, Energy en
     }
     bad_width |= !(w > R(0));
 #pragma unroll
-    for (int d = 0; d < D; ++d) a.x[(long long)d * a.n + c] = x[d];
-    a.energy[c] = e;
-    a.width[c] = w;
+    for (int d = 0; d < D; ++d) state_store(&a.x[(long long)d * a.n + c], x[d]);
+    state_store(&a.energy[c], e);
+    state_store(&a.width[c], w);
   }
   // acceptance tracking: ballot + popcount per sweep, then ONE plain read-modify-write of the wavefront's own
   // slot per launch.  (Same-address atomics serialise at ~12 ns each at the memory side: 2^14 wavefronts adding

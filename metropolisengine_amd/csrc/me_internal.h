@@ -26,6 +26,7 @@ constexpr int kMaxCoeffs = 8;       // small by-value coefficient sets (dense ma
 struct StepLaunch {
   void *x, *energy, *width;
   const void *factor;        // CK_PER_CHAIN: [P][N]; CK_SHARED: [P]
+  const void *factor_full;   // CK_SHARED on pure-real engines: the same factor as a dense [nr][nr] row-major matrix
   const void *coef_device;   // energy coefficients in device memory (device dtype)
   const double *coef_host;   // same, host doubles
   int n_coef;

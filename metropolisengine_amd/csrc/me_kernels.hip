@@ -5,6 +5,7 @@
 #include <type_traits>
 
 #include "me_device.h"
+#include "me_dense_mfma.h"
 
 // User-energy plugin mode: -DME_USER_SOURCE='"file"' -DME_USER_NAME='"name"' compiles the SAME kernels around a
 // user-written device function (include/metropolis_user_energy.h) into a plugin library that registers itself.
@@ -126,6 +127,22 @@ hipError_t step_with(const StepLaunch &l, const Energy &en, hipStream_t stream) 
       return hipErrorNotSupported;
     }
   }
+#if ME_DENSE && !defined(ME_USER_SOURCE)
+  // BASELINE config 4: 64 real parameters, dense quadratic form, fp32 -> matrix-core kernel (me_dense_mfma.h)
+  if constexpr (std::is_same<R, float>::value && NR == 64 && NC == 0 &&
+                std::is_same<Energy, EnergyDense<float, 64, 0>>::value) {
+    if (l.cov_kind == CK_IDENTITY) {
+      hipLaunchKernelGGL(k_step_dense64_mfma<CK_IDENTITY>, grid, block, 0, stream, a, en.a, (const float *)nullptr);
+      return hipGetLastError();
+    }
+    if (l.cov_kind == CK_SHARED) {
+      if (!l.factor_full) return hipErrorInvalidValue;
+      hipLaunchKernelGGL(k_step_dense64_mfma<CK_SHARED>, grid, block, 0, stream, a, en.a, (const float *)l.factor_full);
+      return hipGetLastError();
+    }
+    return hipErrorInvalidValue;
+  } else
+#endif
   switch (l.cov_kind) {
     case CK_IDENTITY: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_IDENTITY>), grid, block, 0, stream, a, en); break;
     case CK_SHARED: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_SHARED>), grid, block, 0, stream, a, en); break;

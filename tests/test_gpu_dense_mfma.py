@@ -1,0 +1,71 @@
+"""GPU tests of the matrix-core path for BASELINE config 4 (64 real parameters, E = x^T A x, float32):
+k_step_dense64_mfma against the float64 oracle (one step) and against the analytic stationary covariance T/2 A^-1."""
+import numpy as np
+import pytest
+
+import metropolisengine_amd as me
+from metropolisengine_amd.distributed import moments_to_statistics, pooled_factor
+from oracle import energies
+from oracle.manychain import ManyChainOracle
+
+pytestmark = pytest.mark.gpu
+
+_M = np.random.default_rng(5).standard_normal((64, 64))
+AMAT = _M @ _M.T / 64 + np.identity(64)
+ASYM = AMAT + 0.05 * np.triu(np.random.default_rng(6).standard_normal((64, 64)), 1)   # not symmetric: catches a transposed operand
+
+
+@pytest.mark.parametrize("matrix", [AMAT, ASYM], ids=["spd", "asymmetric"])
+def test_mfma_energy_one_step_vs_oracle(matrix):
+    n, seed = 4096 + 37, 11          # ragged tail: the last wavefront has shadow lanes
+    x0 = list(np.linspace(-0.3, 0.3, 64))
+    eng = me.MetropolisEngine(me.DenseQuadratic(matrix), None, x0, None, temp=1.0, n_chains=n, seed=seed,
+                              sampling_width=0.1, cov_mode="fixed")
+    ora = ManyChainOracle(64, 0, energies.dense_quadratic(64, 0, matrix), n, seed=seed, temp=1.0,
+                          initial_real_params=x0, sampling_width=0.1)
+    assert np.allclose(eng.energy_total, ora.energy, rtol=2e-6)
+    eng.step_all()
+    ora.step()
+    x, e = eng._get(0), eng.energy_total
+    same = np.all(np.abs(x - ora.x) < 2e-5, axis=1)
+    assert same.mean() > 0.998                              # float32 accept flips only on near-ties
+    assert np.allclose(e[same], ora.energy[same], rtol=1e-5)
+    acc, prop = eng.accept_stats()
+    assert prop == n and abs(acc - ora.accepted) <= 8
+    eng.step_all(3)                                         # fused sweeps run the same code
+    ora.step(3)
+    same = np.all(np.abs(eng._get(0) - ora.x) < 1e-4, axis=1)
+    assert same.mean() > 0.99
+
+
+def test_mfma_stationary_covariance_identity_and_pooled():
+    n = 1 << 13
+    want = 0.5 * np.linalg.inv(AMAT)                        # density exp(-x^T A x / T), T = 1
+    eng = me.MetropolisEngine(me.DenseQuadratic(AMAT), None, [0.0] * 64, None, temp=1.0, n_chains=n, seed=4,
+                              sampling_width=0.2, cov_mode="pooled")
+    eng.step_all(3000)                                      # identity proposal shape so far
+    st = moments_to_statistics(eng.pooled_moments(), 64, 0)
+    tol = 6 * np.max(np.abs(want)) * np.sqrt(2.0 / n)
+    assert np.all(np.abs(st["covariance"] - want) < tol)
+    rate_identity = st["acceptance_rate"]
+    # pooled_shared: one Cholesky factor of the pooled covariance shapes every chain's proposals (L g on the MFMA)
+    eng.set_shared_factor(pooled_factor(st["covariance"], 64, 0))
+    eng.step_all(2000)
+    st2 = moments_to_statistics(eng.pooled_moments(), 64, 0)
+    assert np.all(np.abs(st2["covariance"] - want) < tol)
+    assert 0.15 < rate_identity < 0.5 and 0.15 < st2["acceptance_rate"] < 0.5
+    assert np.all(np.abs(st2["mean"]) < 6 * np.sqrt(np.max(np.diag(want)) / n))
+
+
+def test_mfma_matches_f64_kernel_statistics():
+    """The float64 (VALU) kernels run the same configuration; pooled second moments agree within MC error."""
+    n = 1 << 11
+    kw = dict(temp=1.0, n_chains=n, seed=8, sampling_width=0.2, cov_mode="fixed")
+    f32 = me.MetropolisEngine(me.DenseQuadratic(AMAT), None, [0.0] * 64, None, **kw)
+    f64 = me.MetropolisEngine(me.DenseQuadratic(AMAT), None, [0.0] * 64, None, dtype="f64", **kw)
+    f32.step_all(1500)
+    f64.step_all(1500)
+    a = moments_to_statistics(f32.pooled_moments(), 64, 0)
+    b = moments_to_statistics(f64.pooled_moments(), 64, 0)
+    assert abs(a["acceptance_rate"] - b["acceptance_rate"]) < 0.01
+    assert np.all(np.abs(np.diag(a["covariance"]) - np.diag(b["covariance"])) < 8 * 0.5 * np.sqrt(2.0 / n))
