@@ -296,6 +296,15 @@ int me_create(const me_config *c, me_engine **out) {
     return fail(nullptr, ME_ERR_UNSUPPORTED,
                 "per-chain adaptive covariance is not compiled for these dimensions; use ME_COV_FIXED or ME_COV_POOLED");
 
+  {
+    // the kernels address each field through a buffer descriptor with 32-bit offsets (me_device.h: Field)
+    const long long esz = c->dtype == ME_F32 ? 4 : 8;
+    const long long rows = std::max<long long>(std::max(c->n_real + 2 * c->n_complex, 2 * c->n_real + c->n_complex),
+                                               ks->per_chain_cov ? packed_total(c->n_real, c->n_complex) : 0);
+    if (rows * c->n_chains * esz >= (1ll << 32))
+      return fail(nullptr, ME_ERR_UNSUPPORTED,
+                  "a per-chain field would exceed 4 GiB on this engine; shard the chains over more engines");
+  }
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
     return fail(nullptr, ME_ERR_HIP, "no HIP device available (this library has no CPU fallback)");

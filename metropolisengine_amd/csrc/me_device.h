@@ -54,7 +54,7 @@ struct Num<float> {
   }
   static __device__ __forceinline__ void normal_pair(uint32_t wa, uint32_t wb, float &g0, float &g1) {
     const float u1 = unit(wa), u2 = unit(wb);
-    const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u1)
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u1); raw v_sqrt_f32 (1 ulp) -- the IEEE expansion costs ~10 VALU per draw
     g0 = r * __builtin_amdgcn_cosf(u2);
     g1 = r * __builtin_amdgcn_sinf(u2);
   }
@@ -93,6 +93,40 @@ struct Num<double> {
   static __device__ __forceinline__ double sqrt_(double v) { return sqrt(v); }
   static __device__ __forceinline__ double abs_(double v) { return fabs(v); }
   static __device__ __forceinline__ bool finite(double v) { return isfinite(v); }
+};
+
+// ------------------------------------------------------------------------------------------------ field access
+// A component-major field (rows x n chains) addressed through a buffer descriptor: the row offset travels in a
+// scalar register (soffset = row * n * sizeof(R)) and the chain offset in ONE vector register, so a kernel that
+// touches dozens of rows holds no per-row 64-bit addresses (they cost 2 VGPRs each and were being spilled).
+// Out-of-range accesses are dropped by the hardware range check.  me_create guarantees rows*n*sizeof(R) < 4 GiB.
+template <typename R>
+struct Field {
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned int row_bytes;
+  __device__ __forceinline__ Field(const R *base, long long n, int rows)
+      : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<R *>(base), 0, (unsigned int)(rows * n * (long long)sizeof(R)),
+                                               0x00020000)),
+        row_bytes((unsigned int)(n * (long long)sizeof(R))) {}
+  // chain_off = chain index * sizeof(R)
+  __device__ __forceinline__ R load(int row, unsigned int chain_off) const {
+    if constexpr (sizeof(R) == 4) {
+      return __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b32(rsrc, chain_off, (unsigned int)row * row_bytes, 0));
+    } else {
+      const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, chain_off, (unsigned int)row * row_bytes, 0);
+      return __builtin_bit_cast(R, v);
+    }
+  }
+  __device__ __forceinline__ void store(int row, unsigned int chain_off, R value) const {
+    if constexpr (sizeof(R) == 4) {
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, value), rsrc, chain_off,
+                                            (unsigned int)row * row_bytes, 0);
+    } else {
+      using v2 = decltype(__builtin_amdgcn_raw_buffer_load_b64(rsrc, 0u, 0u, 0));
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2, value), rsrc, chain_off,
+                                            (unsigned int)row * row_bytes, 0);
+    }
+  }
 };
 
 // ------------------------------------------------------------------------------------------------ energies
@@ -202,35 +236,14 @@ __host__ __device__ constexpr int cdiag(int pr, int i) { return pr + i * i + 2 *
 // trajectories, tests/golden/, through the very same proposal / accept / adapt code).
 // Tuning knobs (experiments; defaults are the shipped configuration):
 //   ME_STEP_WAVES_PER_EU  second __launch_bounds__ argument (min waves per SIMD -> VGPR budget); 0 = unset
-//   ME_STEP_NT            1 = non-temporal state loads, 2 = non-temporal state stores, 3 = both
 #ifndef ME_STEP_WAVES_PER_EU
 #define ME_STEP_WAVES_PER_EU 0
-#endif
-#ifndef ME_STEP_NT
-#define ME_STEP_NT 0
 #endif
 #if ME_STEP_WAVES_PER_EU > 0
 #define ME_STEP_BOUNDS __launch_bounds__(kBlockThreads, ME_STEP_WAVES_PER_EU)
 #else
 #define ME_STEP_BOUNDS __launch_bounds__(kBlockThreads)
 #endif
-template <typename T>
-__device__ __forceinline__ T state_load(const T *p) {
-#if ME_STEP_NT & 1
-  return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
-}
-template <typename T>
-__device__ __forceinline__ void state_store(T *p, T v) {
-#if ME_STEP_NT & 2
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
-}
-
 template <typename R, int NR, int NC, class Energy, int CK, bool INJECT = false>
 __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   constexpr int D = NR + 2 * NC;
@@ -242,16 +255,19 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   unsigned int wave_accepted = 0;
   bool bad_energy = false, bad_width = false;
   const long long stride = (long long)gridDim.x * kBlockThreads;
+  const Field<R> fx(a.x, a.n, D), fe(a.energy, a.n, 1), fw(a.width, a.n, 1);
+  const Field<R> ffac(a.factor, a.n, CK == CK_PER_CHAIN ? NR * (NR + 1) / 2 + NC * NC : 0);
   for (long long c = (long long)blockIdx.x * kBlockThreads + threadIdx.x; c < a.n; c += stride) {
+    const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
     R x[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) x[d] = state_load(&a.x[(long long)d * a.n + c]);
-    R e = state_load(&a.energy[c]);
-    R w = state_load(&a.width[c]);
+    for (int d = 0; d < D; ++d) x[d] = fx.load(d, coff);
+    R e = fe.load(0, coff);
+    R w = fw.load(0, coff);
     const unsigned long long gid = a.chain_offset + (unsigned long long)c;
     // CK_PER_CHAIN reads element k at factor[k*n + c] (coalesced); CK_SHARED reads factor[k] (wave-uniform)
     auto fac = [&](int k) -> R {
-      if constexpr (CK == CK_PER_CHAIN) return a.factor[(long long)k * a.n + c];
+      if constexpr (CK == CK_PER_CHAIN) return ffac.load(k, coff);
       else return a.factor[k];
     };
 
@@ -338,9 +354,9 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
     }
     bad_width |= !(w > R(0));
 #pragma unroll
-    for (int d = 0; d < D; ++d) state_store(&a.x[(long long)d * a.n + c], x[d]);
-    state_store(&a.energy[c], e);
-    state_store(&a.width[c], w);
+    for (int d = 0; d < D; ++d) fx.store(d, coff, x[d]);
+    fe.store(0, coff, e);
+    fw.store(0, coff, w);
   }
   // acceptance tracking: ballot + popcount per sweep, then ONE plain read-modify-write of the wavefront's own
   // slot per launch.  (Same-address atomics serialise at ~12 ns each at the memory side: 2^14 wavefronts adding
@@ -396,14 +412,17 @@ __global__ void __launch_bounds__(kBlockThreads) k_measure(MeasureArgs<R> a) {
   using N_ = Num<R>;
   bool bad_pivot = false;
   const long long stride = (long long)gridDim.x * kBlockThreads;
+  const Field<R> fx(a.x, a.n, D), fw(a.width, a.n, 1), fmean(a.mean, a.n, D), fobs(a.obs_mean, a.n, NOBS);
+  const Field<R> fcov(a.cov, a.n, PER_CHAIN_COV ? P : 0), ffac(a.factor, a.n, PER_CHAIN_COV ? P : 0);
   for (long long c = (long long)blockIdx.x * kBlockThreads + threadIdx.x; c < a.n; c += stride) {
+    const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
     R x[D], delta[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      x[d] = a.x[(long long)d * a.n + c];
-      const R mu = a.mean[(long long)d * a.n + c];
+      x[d] = fx.load(d, coff);
+      const R mu = fmean.load(d, coff);
       delta[d] = x[d] - mu;
-      a.mean[(long long)d * a.n + c] = mu * a.keep + x[d] * a.inv_i;   // :404-410
+      fmean.store(d, coff, mu * a.keep + x[d] * a.inv_i);   // :404-410
     }
     // observables [|x_r|, |z_c|, x_r^2] and their running mean (:458-463, :412-414)
 #pragma unroll
@@ -412,12 +431,12 @@ __global__ void __launch_bounds__(kBlockThreads) k_measure(MeasureArgs<R> a) {
       if (k < NR) o = N_::abs_(x[k]);
       else if (k < NR + NC) o = N_::sqrt_(x[k] * x[k] + x[k + NC] * x[k + NC]);
       else o = x[k - NR - NC] * x[k - NR - NC];
-      const R m = a.obs_mean[(long long)k * a.n + c];
-      a.obs_mean[(long long)k * a.n + c] = m * a.keep + o * a.inv_i;
+      const R m = fobs.load(k, coff);
+      fobs.store(k, coff, m * a.keep + o * a.inv_i);
     }
     if constexpr (PER_CHAIN_COV) {
       if (a.update_cov) {
-        const R w = a.width[c];
+        const R w = fw.load(0, coff);
         const R eps = w * w * a.inv_i;   // :418, :425 -- the shared width in mixed engines (:436-437)
         R m[P];
 #pragma unroll
@@ -425,9 +444,9 @@ __global__ void __launch_bounds__(kBlockThreads) k_measure(MeasureArgs<R> a) {
 #pragma unroll
           for (int j = 0; j <= i; ++j) {
             const int k = tri(i, j);
-            R v = a.cov[(long long)k * a.n + c] * a.cov_keep + delta[i] * delta[j] * a.inv_i;
+            R v = fcov.load(k, coff) * a.cov_keep + delta[i] * delta[j] * a.inv_i;
             if (i == j) v += eps;
-            a.cov[(long long)k * a.n + c] = v;
+            fcov.store(k, coff, v);
             m[k] = v;
           }
 #pragma unroll
@@ -437,16 +456,16 @@ __global__ void __launch_bounds__(kBlockThreads) k_measure(MeasureArgs<R> a) {
           for (int j = 0; j < i; ++j) {
             const R aj = delta[NR + j], bj = delta[NR + NC + j];
             const int kr = cre(PR, i, j), ki = cim(PR, i, j);
-            const R vr = a.cov[(long long)kr * a.n + c] * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
-            const R vi = a.cov[(long long)ki * a.n + c] * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
-            a.cov[(long long)kr * a.n + c] = vr;
-            a.cov[(long long)ki * a.n + c] = vi;
+            const R vr = fcov.load(kr, coff) * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
+            const R vi = fcov.load(ki, coff) * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
+            fcov.store(kr, coff, vr);
+            fcov.store(ki, coff, vi);
             m[kr] = vr;
             m[ki] = -vi;   // the proposals use conj(K) (quirk Q3, :292-298)
           }
           const int kd = cdiag(PR, i);
-          const R vd = a.cov[(long long)kd * a.n + c] * a.cov_keep + (ai * ai + bi * bi) * a.inv_i + eps;
-          a.cov[(long long)kd * a.n + c] = vd;
+          const R vd = fcov.load(kd, coff) * a.cov_keep + (ai * ai + bi * bi) * a.inv_i + eps;
+          fcov.store(kd, coff, vd);
           m[kd] = vd;
         }
         if (a.write_factor) {
@@ -494,7 +513,7 @@ __global__ void __launch_bounds__(kBlockThreads) k_measure(MeasureArgs<R> a) {
             }
           }
 #pragma unroll
-          for (int k = 0; k < P; ++k) a.factor[(long long)k * a.n + c] = m[k];
+          for (int k = 0; k < P; ++k) ffac.store(k, coff, m[k]);
         }
       }
     }

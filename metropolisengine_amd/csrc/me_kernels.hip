@@ -131,14 +131,11 @@ hipError_t step_with(const StepLaunch &l, const Energy &en, hipStream_t stream) 
   // BASELINE config 4: 64 real parameters, dense quadratic form, fp32 -> matrix-core kernel (me_dense_mfma.h)
   if constexpr (std::is_same<R, float>::value && NR == 64 && NC == 0 &&
                 std::is_same<Energy, EnergyDense<float, 64, 0>>::value) {
-    if (l.cov_kind == CK_IDENTITY) {
-      hipLaunchKernelGGL(k_step_dense64_mfma<CK_IDENTITY>, grid, block, 0, stream, a, en.a, (const float *)nullptr);
-      return hipGetLastError();
-    }
+    if (l.cov_kind == CK_IDENTITY)
+      return launch_step_dense64_mfma<CK_IDENTITY>(a, en.a, nullptr, l.grid_blocks, stream);
     if (l.cov_kind == CK_SHARED) {
       if (!l.factor_full) return hipErrorInvalidValue;
-      hipLaunchKernelGGL(k_step_dense64_mfma<CK_SHARED>, grid, block, 0, stream, a, en.a, (const float *)l.factor_full);
-      return hipGetLastError();
+      return launch_step_dense64_mfma<CK_SHARED>(a, en.a, (const float *)l.factor_full, l.grid_blocks, stream);
     }
     return hipErrorInvalidValue;
   } else

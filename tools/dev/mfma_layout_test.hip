@@ -16,7 +16,7 @@ __global__ void k_test(const float *m, const float *x, float *y, int lower) {
   if (threadIdx.x >= 64) return;
   float v[64], out[64];
   for (int d = 0; d < 64; ++d) v[d] = x[d * 64 + lane];
-  wave_matmul_64(frag, v, out, lane, lower != 0);
+  wave_matmul_64(frag, [&](int b, int t, float (&q)[4]) { if (t < 4) q[t] = v[4 * b + t]; }, out, lane, lower != 0);
   for (int d = 0; d < 64; ++d) y[d * 64 + lane] = out[d];
 }
 
