@@ -115,10 +115,42 @@ def build_user_energy(source, name, n_real, n_complex, force=False, per_chain=Tr
     return out
 
 
+def dims_plugin_path(n_real, n_complex):
+    return os.path.join(LIB_DIR, "libme_dims_%d_%d.so" % (n_real, n_complex))
+
+
+MAX_PACKED_IN_REGISTERS = 160     # per-chain covariance / factor kernels keep the packed matrix in registers
+
+
+def build_dims(n_real, n_complex, force=False):
+    """Compile the kernel set for a (n_real, n_complex) pair that is not in KERNEL_DIMS into a plugin library.
+
+    The chain state is register-resident, so the dimensions are compile-time constants; any other size is one
+    hipcc run (~10-30 s, cached in lib/) away.  Returns the plugin path; load it with ``me_load_plugin``.
+    """
+    build(verbose=False)
+    out = dims_plugin_path(n_real, n_complex)
+    deps = [os.path.join(CSRC, "me_kernels.hip"), LIB_PATH] + \
+           [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    if not force and _newer(out, deps):
+        return out
+    d = n_real + 2 * n_complex
+    packed = n_real * (n_real + 1) // 2 + n_complex * n_complex
+    if d > 96:
+        raise RuntimeError("register-resident kernels support at most 96 real degrees of freedom (got %d)" % d)
+    inc = os.path.join(os.path.dirname(PKG_DIR), "include")
+    _run([hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-I", inc,
+          "-DME_NR=%d" % n_real, "-DME_NC=%d" % n_complex, "-DME_DENSE=%d" % int(d <= 24),
+          "-DME_PER_CHAIN=%d" % int(packed <= MAX_PACKED_IN_REGISTERS),
+          os.path.join(CSRC, "me_kernels.hip"), "-o", out, "-L", LIB_DIR, "-lmetropolis_hip", "-Wl,-rpath,$ORIGIN"])
+    return out
+
+
 def build_examples(force=False):
-    """The shipped example plugin: cylinder-style surrogate for BASELINE config 5 (2 real + 7 complex)."""
+    """The shipped plugins: the cylinder-style user energy for BASELINE config 5 (2 real + 7 complex) and one
+    kernel set outside KERNEL_DIMS, (3, 2), which exercises the compile-on-demand path of build_dims."""
     src = os.path.join(os.path.dirname(PKG_DIR), "examples", "user_energy_cylinder.h")
-    return [build_user_energy(src, "cylinder", 2, 7, force=force)]
+    return [build_user_energy(src, "cylinder", 2, 7, force=force), build_dims(3, 2, force=force)]
 
 
 if __name__ == "__main__":

@@ -162,6 +162,11 @@ class MetropolisEngine:
             keep.append(c_ri)
         handle = ctypes.c_void_p()
         self._handle = None
+        if (not hasattr(energy_functions, "ensure_loaded")
+                and not self._lib.me_supported(cfg.dtype, nr, nc, _capi.ENERGY_ISO_QUAD)):
+            # dimensions outside the prebuilt set: compile this (nr, nc) kernel set once (hipcc) and load it
+            from . import build
+            _capi.check(self._lib.me_load_plugin(build.build_dims(nr, nc).encode()))
         _capi.check(self._lib.me_create(ctypes.byref(cfg), ctypes.byref(handle)))
         self._handle = handle
         alpha, ratio, m = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()

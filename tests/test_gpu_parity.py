@@ -292,8 +292,8 @@ def test_pooled_shared_covariance_mode():
 
 
 def test_errors_on_gpu():
-    with pytest.raises(NotImplementedError):
-        me.MetropolisEngine(me.IsoQuadratic(), initial_real_params=[0.0] * 5, temp=1.0)        # no (5,0) kernels
+    with pytest.raises(RuntimeError):
+        me.MetropolisEngine(me.IsoQuadratic(), initial_real_params=[0.0] * 100, temp=1.0)      # beyond register kernels
     with pytest.raises(NotImplementedError):
         me.MetropolisEngine(me.IsoQuadratic(), initial_real_params=[0.0] * 64, temp=1.0)       # needs cov_mode fixed
     eng = me.MetropolisEngine(me.IsoQuadratic(), initial_real_params=[0.0] * 64, temp=1.0, cov_mode="fixed",
@@ -367,5 +367,24 @@ def test_user_energy_plugin_matches_builtin_and_oracle():
         eng.measure()
         ora.measure()
     assert np.allclose(eng._get(0), ora.x, rtol=0, atol=TOL)
+    assert np.allclose(eng.covariance_matrix_complex, ora.cov_complex, rtol=0, atol=TOL)
+    assert eng.accept_stats() == (ora.accepted, ora.proposed)
+
+
+def test_dimensions_outside_the_prebuilt_set():
+    """(3 real, 2 complex) is not in build.KERNEL_DIMS: the engine compiles / loads a kernel-set plugin on demand
+    (prebuilt by __graft_entry__.build()) and must follow the oracle like any other size."""
+    real0, cplx0 = [0.1, -0.2, 0.3], [0.1 + 0.1j, -0.2j]
+    a, b = (1.0, 2.0, 0.5), (1.5, 3.0)
+    eng = me.MetropolisEngine(me.DiagQuadratic(a, b), None, real0, cplx0, temp=0.8, n_chains=128, seed=77, dtype="f64")
+    ora = ManyChainOracle(3, 2, energies.diag_quadratic(3, 2, a, b), 128, seed=77, temp=0.8,
+                          initial_real_params=real0, initial_complex_params=cplx0)
+    for _ in range(60):
+        eng.step_all(3)
+        ora.step(3)
+        eng.measure()
+        ora.measure()
+    assert np.allclose(eng._get(0), ora.x, rtol=0, atol=TOL)
+    assert np.allclose(eng.covariance_matrix_real, ora.cov_real, rtol=0, atol=TOL)
     assert np.allclose(eng.covariance_matrix_complex, ora.cov_complex, rtol=0, atol=TOL)
     assert eng.accept_stats() == (ora.accepted, ora.proposed)
