@@ -64,17 +64,35 @@ class InjectedStreams:
         return mean + np.concatenate((v.real, v.imag))
 
     def _uniform(self, lo, hi):
-        assert (lo, hi) == (0, 1)
-        return float(self.uniforms[self.step])
+        # uniforms[step] = [accept (Gaussian step, or magnitude stage), phase_0..phase_{nc-1}, accept (phase stage)]
+        if (lo, hi) == (0, 1):                                  # the accept draw, metropolis_engine.py:335
+            slot = 0 if self.phase_calls == 0 else self.nc + 1
+            return float(self.uniforms[self.step, slot])
+        assert abs(lo + math.pi) < 1e-15 and abs(hi - math.pi) < 1e-15    # modify_phase, :317
+        self.phase_calls += 1
+        return lo + (hi - lo) * float(self.uniforms[self.step, self.phase_calls])
+
+    def _gauss(self, mu, sigma):                                # modify_magnitude, :310
+        z = self.normals[self.step, self.gauss_calls]
+        self.gauss_calls += 1
+        return mu + z * sigma
+
+    def next_step(self):
+        self.step += 1
+        self.phase_calls = 0
+        self.gauss_calls = 0
 
     def __enter__(self):
-        self._saved = (np.random.multivariate_normal, random.uniform)
+        self._saved = (np.random.multivariate_normal, random.uniform, random.gauss)
         np.random.multivariate_normal = self._mvn
         random.uniform = self._uniform
+        random.gauss = self._gauss
+        self.phase_calls = 0
+        self.gauss_calls = 0
         return self
 
     def __exit__(self, *exc):
-        np.random.multivariate_normal, random.uniform = self._saved
+        np.random.multivariate_normal, random.uniform, random.gauss = self._saved
 
 
 def build_engine(me, spec, **extra):
@@ -98,17 +116,20 @@ def run_scenario(me, name, spec, stream_seed):
     total = scenarios.n_steps(spec)
     rng = np.random.default_rng(stream_seed)
     normals = rng.standard_normal((total, nr + 2 * nc))
-    uniforms = rng.random(total)
+    uniforms = rng.random((total, nc + 2))
     rec = {k: [] for k in ("accept", "real_params", "complex_params", "real_width", "complex_width",
                            "energy_total", "energy_terms", "real_mean", "complex_mean", "cov_real",
                            "cov_complex", "observables_mean")}
     with InjectedStreams(normals, uniforms, nr, nc) as inj:
-        engine = build_engine(me, spec)
+        extra = {"complex_sample_method": spec["method"]} if "method" in spec else {}
+        engine = build_engine(me, spec, **extra)
         term_names = sorted(engine.energy)
+        stepper = {"all": engine.step_all, "real": engine.step_real_group, "complex": engine.step_complex_group}
         for _ in range(spec["n_measures"]):
-            for _ in range(spec["steps_per_measure"]):
-                rec["accept"].append(bool(engine.step_all()))
-                inj.step += 1
+            for op in scenarios.ops(spec)[:-1]:
+                took = stepper[op]()                            # None for a magnitude-phase pair (:175-176)
+                rec["accept"].append(-1 if took is None else int(bool(took)))
+                inj.next_step()
                 rec["real_params"].append(np.array(engine.real_params, dtype=np.float64))
                 rec["complex_params"].append(np.array(engine.complex_params, dtype=np.complex128))
                 rec["real_width"].append(float(engine.real_group_sampling_width))
@@ -130,7 +151,7 @@ def run_scenario(me, name, spec, stream_seed):
     path = os.path.join(GOLDEN_DIR, "traj_%s.npz" % name)
     np.savez_compressed(path, **out)
     print("%-26s steps=%5d accepts=%5d  -> %s (%d bytes)"
-          % (name, total, int(np.sum(out["accept"])), os.path.relpath(path, ROOT), os.path.getsize(path)))
+          % (name, total, int(np.sum(out["accept"] > 0)), os.path.relpath(path, ROOT), os.path.getsize(path)))
 
 
 def seeded_anchors(me):

@@ -50,6 +50,7 @@ class ManyChainOracle:
         self.energy = np.asarray(energy(self.x), dtype=np.float64).copy()
         self.width_real = np.full(n_chains, float(sampling_width))
         self.width_complex = np.full(n_chains, float(sampling_width))
+        self.width_all = np.full(n_chains, float(sampling_width))      # mixed engines' shared sampling_width
         self.step_index = 0
         self.measure_step_counter = 1
         self.accepted = 0
@@ -79,21 +80,13 @@ class ManyChainOracle:
                                else np.zeros((self.n_chains, 0, 0), dtype=np.complex128))
 
     # ------------------------------------------------------------------ step
-    def step(self, n_sweeps=1):
+    def step(self, n_sweeps=1, group="all"):
+        """``group`` = "all" (step_all, :241-259), "real" / "complex" (step_*_group called directly, :209-239)."""
         for _ in range(n_sweeps):
-            self._sweep()
+            self._sweep(group)
 
-    def _sweep(self):
-        nr, nc = self.nr, self.nc
-        g, u = philox.step_draws(self.seed, self.chain_ids, self.step_index, self.dim)
-        prop = self.x.copy()
-        if nr:
-            prop[:, :nr] += self.width_real[:, None] * np.einsum("nij,nj->ni", self.factor_real, g[:, :nr])
-        if nc:
-            w = (g[:, nr:nr + nc] + 1j * g[:, nr + nc:]) / math.sqrt(2.0)
-            dz = self.width_complex[:, None] * np.einsum("nij,nj->ni", self.factor_complex, w)
-            prop[:, nr:nr + nc] += dz.real
-            prop[:, nr + nc:] += dz.imag
+    def _decide(self, prop, u):
+        """Wall, energy, accept rule (:247-252, :319-338) and commit for a proposed state; returns the accept mask."""
         rejected = self.reject_fn(prop) if self.reject_fn is not None else np.zeros(self.n_chains, dtype=bool)
         new_energy = np.asarray(self.energy_fn(prop), dtype=np.float64)
         diff = new_energy - self.energy
@@ -105,24 +98,77 @@ class ManyChainOracle:
         accept = ~rejected & ((diff <= 0) | uphill_ok)
         self.x[accept] = prop[accept]
         self.energy[accept] = new_energy[accept]
-
-        damping = max(self.measure_step_counter / self.m, ADAPTATION_FLOOR)
-        p = self.target_acceptance
-
-        def adapt(width):
-            scale = width * self.ratio
-            return np.where(accept, width + scale * (1 - p) / damping, width - scale * p / damping)
-        if self.mode == "mixed":
-            self.width_real = adapt(self.width_real)
-            self.width_complex = self.width_real.copy()
-        elif self.mode == "real":
-            self.width_real = adapt(self.width_real)
-        else:
-            self.width_complex = adapt(self.width_complex)
         self.last_accept = accept
         self.accepted += int(np.sum(accept))
         self.proposed += self.n_chains
+        return accept
+
+    def _adapt(self, width, accept):
+        damping = max(self.measure_step_counter / self.m, ADAPTATION_FLOOR)
+        p = self.target_acceptance
+        scale = width * self.ratio
+        return np.where(accept, width + scale * (1 - p) / damping, width - scale * p / damping)
+
+    def _sweep(self, group="all"):
+        nr, nc = self.nr, self.nc
+        # the word layout of a step does not depend on which group moves: normal i belongs to coordinate i
+        g, u = philox.step_draws(self.seed, self.chain_ids, self.step_index, self.dim)
+        prop = self.x.copy()
+        if nr and group in ("all", "real"):
+            prop[:, :nr] += self.width_real[:, None] * np.einsum("nij,nj->ni", self.factor_real, g[:, :nr])
+        if nc and group in ("all", "complex"):
+            w = (g[:, nr:nr + nc] + 1j * g[:, nr + nc:]) / math.sqrt(2.0)
+            dz = self.width_complex[:, None] * np.einsum("nij,nj->ni", self.factor_complex, w)
+            prop[:, nr:nr + nc] += dz.real
+            prop[:, nr + nc:] += dz.imag
+        accept = self._decide(prop, u)
+        if group == "all" and self.mode == "mixed":
+            # one shared width is adapted and mirrored into both group widths (:429-438)
+            self.width_all = self._adapt(self.width_all, accept)
+            self.width_real = self.width_all.copy()
+            self.width_complex = self.width_all.copy()
+        elif (group == "all" and self.mode == "real") or group == "real":
+            self.width_real = self._adapt(self.width_real, accept)          # :440-446
+        else:
+            self.width_complex = self._adapt(self.width_complex, accept)    # :449-456
         self.step_index += 1
+
+    def step_magnitude_phase(self, n_sweeps=1):
+        """``step_complex_group`` under ``complex_sample_method="magnitude-phase"`` (:168-207, :304-317).
+
+        Stream words of one step: Box-Muller pairs ``0 .. W1-1`` (``W1 = 2 ceil(nc/2)``) give the ``nc`` magnitude
+        normals, word ``W1`` the accept draw of the magnitude stage, words ``W1+1 .. W1+nc`` the phases
+        (``-pi + 2 pi u``) and word ``W1+nc+1`` the accept draw of the phase stage.
+        """
+        nr, nc = self.nr, self.nc
+        for _ in range(n_sweeps):
+            w1 = philox.n_normal_words(nc)
+            words = philox.step_words(self.seed, self.chain_ids, self.step_index, w1 + nc + 2)
+            unit = philox.unit_open(words)
+            r = np.sqrt(-2.0 * np.log(unit[:, 0:w1:2]))
+            theta = (2.0 * np.pi) * unit[:, 1:w1:2]
+            g = np.empty((self.n_chains, w1))
+            g[:, 0::2] = r * np.cos(theta)
+            g[:, 1::2] = r * np.sin(theta)
+            g = g[:, :nc]
+            # --- magnitude stage: m' = m + (sigma_c^2 Re K_jj) g at fixed phase; the width adapts (:178-192)
+            z = self.complex_params()
+            mag = np.abs(z)
+            direction = np.where(mag > 0, z / np.where(mag > 0, mag, 1.0), 1.0 + 0j)       # polar(0) = (0, phase 0)
+            spread = self.width_complex[:, None] ** 2 * np.real(np.einsum("njj->nj", self.cov_complex))
+            znew = (mag + spread * g) * direction
+            prop = self.x.copy()
+            prop[:, nr:nr + nc], prop[:, nr + nc:] = znew.real, znew.imag
+            accept = self._decide(prop, unit[:, w1])
+            self.width_complex = self._adapt(self.width_complex, accept)
+            # --- phase stage: every phase redrawn in (-pi, pi) at fixed magnitude; no width update (:194-207)
+            z = self.complex_params()
+            phases = -np.pi + 2.0 * np.pi * unit[:, w1 + 1:w1 + 1 + nc]
+            znew = np.abs(z) * (np.cos(phases) + 1j * np.sin(phases))
+            prop = self.x.copy()
+            prop[:, nr:nr + nc], prop[:, nr + nc:] = znew.real, znew.imag
+            self._decide(prop, unit[:, w1 + nc + 1])
+            self.step_index += 1
 
     # ------------------------------------------------------------------ measure
     def measure(self):

@@ -75,11 +75,28 @@ SCENARIOS = {
                                 steps_per_measure=3, n_measures=100, reject=_wall),
     "zero_temp_2real": dict(energy=_diag(a=(1.0, 3.0)), real=[1.0, -1.0], cplx=None, temp=0.0,
                             steps_per_measure=5, n_measures=60),
+    # group-wise stepping of mixed engines (metropolis_engine.py:209-239 called directly, as the author's cylinder
+    # driver does: separate real / complex widths in exampledata.csv) and the magnitude-phase sampler (:168-207)
+    "groups_2real_2complex": dict(energy=_coupled, real=[0.1, -0.1], cplx=[0.2 + 0.1j, -0.1 + 0.3j], temp=1.0,
+                                  ops=("real", "complex", "all", "real", "measure"), n_measures=120),
+    "groups_landau_terms": dict(energy=landau_terms(), real=[0.0, 0.0], cplx=[0j], temp=0.1,
+                                ops=("real", "complex", "real", "complex", "measure"), n_measures=100),
+    "magphase_1real_2complex": dict(energy=_diag(a=(0.5,), b=(1.0, 3.0)), real=[0.2], cplx=[0.3 + 0.1j, 0.2j], temp=0.5,
+                                    ops=("real", "complex", "measure"), n_measures=150, method="magnitude-phase"),
+    "magphase_2complex": dict(energy=_diag(b=(1.0, 2.0)), real=None, cplx=[0.3 + 0.1j, 0.2j], temp=0.5,
+                              ops=("complex", "complex", "all", "measure"), n_measures=120, method="magnitude-phase"),
 }
 
 
+def ops(spec):
+    """One cycle of the scenario's protocol: step kinds ("all", "real", "complex") ending in "measure"."""
+    if "ops" in spec:
+        return tuple(spec["ops"])
+    return ("all",) * spec["steps_per_measure"] + ("measure",)
+
+
 def n_steps(spec):
-    return spec["steps_per_measure"] * spec["n_measures"]
+    return sum(op != "measure" for op in ops(spec)) * spec["n_measures"]
 
 
 def dims(spec):
