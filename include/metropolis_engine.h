@@ -82,7 +82,7 @@ typedef enum me_cov_mode {
 typedef enum me_field {
   ME_FIELD_PARAMS = 0,   /* [D]  current state */
   ME_FIELD_ENERGY = 1,   /* [1]  energy of the current state */
-  ME_FIELD_WIDTH = 2,    /* [1]  the adapting sampling width (shared width in mixed engines) */
+  ME_FIELD_WIDTH = 2,    /* [1] the group's sampling width; mixed engines [3]: sampling_width, real group, complex group */
   ME_FIELD_MEAN = 3,     /* [D]  running mean */
   ME_FIELD_COV = 4,      /* [P]  running covariance, packed: real block row-major lower triangle, then for
                                  each complex row i: (Re,Im) of K_ij for j<i, then K_ii */
@@ -127,12 +127,26 @@ int me_destroy(me_engine *engine);
 /* n_sweeps fused propose->energy->accept->adapt sweeps over all chains in one launch; n_sweeps = 1 is one
  * reference step_all(). */
 int me_step(me_engine *engine, int32_t n_sweeps);
+/* Step kinds beyond step_all: a mixed engine's step_real_group / step_complex_group called directly
+ * (metropolis_engine.py:225-239, :209-223: only that group moves and only its own width adapts) and the
+ * magnitude-phase pair that replaces step_complex_group under complex_sample_method="magnitude-phase"
+ * (:168-207; two accept decisions per step).  On pure-real / pure-complex engines the group kinds are step_all
+ * (:46, :56).  me_step(e, k) == me_step_kind(e, ME_STEP_ALL, k). */
+typedef enum me_step_kind_t {
+  ME_STEP_ALL = 0,
+  ME_STEP_REAL_GROUP = 1,
+  ME_STEP_COMPLEX_GROUP = 2,
+  ME_STEP_COMPLEX_MAGNITUDE_PHASE = 3
+} me_step_kind_t;
+int me_step_kind(me_engine *engine, int32_t kind, int32_t n_sweeps);
 int me_measure(me_engine *engine);
 /* Test hook (float64 engines): the same step with the random draws supplied by the caller instead of Philox --
- * normals [n_sweeps][n_chains][D] standard normals, uniforms [n_sweeps][n_chains] accept draws.  This is how the
- * reference's golden trajectories (tests/golden/, injected-stream runs of metropolis_engine.py) are replayed
- * through the HIP kernels.  Synchronous. */
-int me_step_injected(me_engine *engine, int32_t n_sweeps, const double *normals, const double *uniforms);
+ * for the Gaussian kinds normals [n_sweeps][n_chains][D] standard normals and uniforms [n_sweeps][n_chains][1] accept
+ * draws; for ME_STEP_COMPLEX_MAGNITUDE_PHASE normals [n_sweeps][n_chains][nc] and uniforms [n_sweeps][n_chains][nc+2]
+ * = {accept (magnitude stage), nc phases in (0,1), accept (phase stage)}.  This is how the reference's golden
+ * trajectories (tests/golden/, injected-stream runs of metropolis_engine.py) are replayed through the HIP kernels.
+ * Synchronous. */
+int me_step_injected(me_engine *engine, int32_t kind, int32_t n_sweeps, const double *normals, const double *uniforms);
 
 int me_field_components(me_engine *engine, int32_t field, int32_t *n_components);
 /* Copy chains [chain_begin, chain_begin + n_chains) of a field to/from host doubles [chain][component]. */

@@ -14,6 +14,7 @@ ME_F32, ME_F64 = 0, 1
 (ENERGY_ISO_QUAD, ENERGY_DIAG_QUAD, ENERGY_DENSE_QUAD, ENERGY_LANDAU_TOY, ENERGY_CYLINDER, ENERGY_USER,
  ENERGY_USER_INDIRECT) = range(7)
 REJECT_NONE, REJECT_ABS_REAL0_GE = 0, 1
+STEP_ALL, STEP_REAL_GROUP, STEP_COMPLEX_GROUP, STEP_COMPLEX_MAGNITUDE_PHASE = range(4)
 COV_REFERENCE, COV_FIXED, COV_POOLED = 0, 1, 2
 (FIELD_PARAMS, FIELD_ENERGY, FIELD_WIDTH, FIELD_MEAN, FIELD_COV, FIELD_OBS_MEAN, FIELD_FACTOR) = range(7)
 
@@ -44,7 +45,8 @@ SYMBOLS = {
     "me_destroy": (ctypes.c_int, [_H]),
     "me_step": (ctypes.c_int, [_H, ctypes.c_int32]),
     "me_measure": (ctypes.c_int, [_H]),
-    "me_step_injected": (ctypes.c_int, [_H, ctypes.c_int32, _dp, _dp]),
+    "me_step_kind": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32]),
+    "me_step_injected": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32, _dp, _dp]),
     "me_field_components": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
     "me_get": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, _dp]),
     "me_set": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, _dp]),

@@ -122,6 +122,8 @@ struct me_engine {
   unsigned long long *accept_slots = nullptr, *accept_total = nullptr;
   long long n_slots = 0;
   unsigned long long proposed = 0;
+  int width_rows = 1;           // 3 for mixed engines: [sampling_width, real group, complex group]
+  bool widths_synced = true;    // mixed engines: rows 1, 2 are implied equal to row 0 (state after a step_all)
   unsigned int *status = nullptr;
   double *pool_dev = nullptr;
   std::string err;
@@ -166,7 +168,7 @@ int field_info(me_engine *e, int field, void **ptr, int *comps) {
   switch (field) {
     case ME_FIELD_PARAMS: *ptr = e->x; *comps = e->d; return ME_OK;
     case ME_FIELD_ENERGY: *ptr = e->energy; *comps = 1; return ME_OK;
-    case ME_FIELD_WIDTH: *ptr = e->width; *comps = 1; return ME_OK;
+    case ME_FIELD_WIDTH: *ptr = e->width; *comps = e->width_rows; return ME_OK;
     case ME_FIELD_MEAN: *ptr = e->mean; *comps = e->d; return ME_OK;
     case ME_FIELD_OBS_MEAN: *ptr = e->obs_mean; *comps = e->nobs; return ME_OK;
     case ME_FIELD_COV:
@@ -220,6 +222,9 @@ void fill_step_launch(me_engine *e, StepLaunch &l, int n_sweeps) {
   l.n_coef = (int)e->coef.size();
   l.inj_normals = nullptr;
   l.inj_uniforms = nullptr;
+  l.group = GROUP_ALL;
+  l.split_widths = (e->width_rows == 3 && !e->widths_synced) ? 1 : 0;
+  l.cov = e->cov;
   l.accept_slots = e->accept_slots;
   l.status = e->status;
   l.n = e->n;
@@ -353,7 +358,8 @@ int me_create(const me_config *c, me_engine **out) {
   const size_t n = (size_t)e->n, es = e->esize;
   ME_CREATE_HIP(hipMalloc(&e->x, n * e->d * es));
   ME_CREATE_HIP(hipMalloc(&e->energy, n * es));
-  ME_CREATE_HIP(hipMalloc(&e->width, n * es));
+  e->width_rows = (e->nr > 0 && e->nc > 0) ? 3 : 1;
+  ME_CREATE_HIP(hipMalloc(&e->width, n * e->width_rows * es));
   ME_CREATE_HIP(hipMalloc(&e->mean, n * e->d * es));
   ME_CREATE_HIP(hipMalloc(&e->obs_mean, n * e->nobs * es));
   if (ks->per_chain_cov) {
@@ -416,7 +422,7 @@ int me_create(const me_config *c, me_engine **out) {
     return fail(nullptr, ME_ERR_INVALID, "initial covariance matrix is not positive definite (metropolis_engine.py:270)");
   }
   int rc = ME_OK;
-  std::vector<double> width_row(1, c->sampling_width);
+  std::vector<double> width_row((size_t)e->width_rows, c->sampling_width);
   if ((rc = broadcast(e, e->x, init)) || (rc = broadcast(e, e->mean, init)) || (rc = broadcast(e, e->obs_mean, obs)) ||
       (rc = broadcast(e, e->width, width_row)) || (e->cov && (rc = broadcast(e, e->cov, c0))) ||
       (e->factor && (rc = broadcast(e, e->factor, f0)))) {
@@ -480,29 +486,86 @@ int me_recompute_energy(me_engine *e) {
   return ME_OK;
 }
 
-int me_step(me_engine *e, int32_t n_sweeps) {
-  if (!e) return ME_ERR_INVALID;
-  if (n_sweeps <= 0) return fail(e, ME_ERR_INVALID, "n_sweeps must be positive");
-  ME_HIP(e, hipSetDevice(e->device));
-  StepLaunch l;
-  fill_step_launch(e, l, n_sweeps);
-  ME_HIP(e, e->ks->step(l, e->stream));
-  e->step_index += (unsigned long long)n_sweeps;
-    e->proposed += (unsigned long long)e->n * (unsigned long long)n_sweeps;
+// Mixed engines keep three widths per chain [sampling_width, real group, complex group].  After a step_all the
+// group rows are implied equal to row 0 (:436-437) and are not written; before the first group-wise launch they
+// are materialised here.
+static int split_widths(me_engine *e) {
+  if (e->width_rows != 3 || !e->widths_synced) return ME_OK;
+  const size_t row = (size_t)e->n * e->esize;
+  for (int r = 1; r <= 2; ++r)
+    ME_HIP(e, hipMemcpyAsync((unsigned char *)e->width + r * row, e->width, row, hipMemcpyDeviceToDevice, e->stream));
+  e->widths_synced = false;
   return ME_OK;
 }
 
-int me_step_injected(me_engine *e, int32_t n_sweeps, const double *normals, const double *uniforms) {
+// kind: 0 = step_all, 1 = real group, 2 = complex group (Gaussian), 3 = magnitude-phase pair on the complex group
+static int resolve_step_kind(me_engine *e, int kind, int *group, bool *magphase) {
+  *magphase = false;
+  *group = GROUP_ALL;
+  const bool mixed = e->nr > 0 && e->nc > 0;
+  switch (kind) {
+    case ME_STEP_ALL: return ME_OK;
+    case ME_STEP_REAL_GROUP:
+      if (e->nr == 0) return fail(e, ME_ERR_INVALID, "this engine has no real parameters");
+      *group = mixed ? GROUP_REAL : GROUP_ALL;     // pure-real engines: step_all IS step_real_group (:56)
+      return ME_OK;
+    case ME_STEP_COMPLEX_GROUP:
+      if (e->nc == 0) return fail(e, ME_ERR_INVALID, "this engine has no complex parameters");
+      *group = mixed ? GROUP_COMPLEX : GROUP_ALL;  // :46
+      return ME_OK;
+    case ME_STEP_COMPLEX_MAGNITUDE_PHASE:
+      if (e->nc == 0) return fail(e, ME_ERR_INVALID, "this engine has no complex parameters");
+      if (!e->ks->magphase || !e->cov)
+        return fail(e, ME_ERR_UNSUPPORTED, "the magnitude-phase sampler needs the per-chain covariance kernels");
+      *magphase = true;
+      return ME_OK;
+    default: return fail(e, ME_ERR_INVALID, "unknown step kind");
+  }
+}
+
+static int launch_step_kind(me_engine *e, int kind, int n_sweeps, const void *inj_normals, const void *inj_uniforms) {
+  int group;
+  bool magphase;
+  int rc = resolve_step_kind(e, kind, &group, &magphase);
+  if (rc != ME_OK) return rc;
+  if ((group != GROUP_ALL || magphase) && (rc = split_widths(e)) != ME_OK) return rc;
+  StepLaunch l;
+  fill_step_launch(e, l, n_sweeps);
+  l.group = group;
+  l.inj_normals = inj_normals;
+  l.inj_uniforms = inj_uniforms;
+  hipError_t err = magphase ? e->ks->magphase(l, e->stream) : e->ks->step(l, e->stream);
+  if (err == hipErrorNotSupported) return fail(e, ME_ERR_UNSUPPORTED, "this step kind is not compiled for this engine");
+  ME_HIP(e, err);
+  if (group == GROUP_ALL && !magphase) e->widths_synced = true;   // step_all mirrors row 0 into the group widths
+  e->step_index += (unsigned long long)n_sweeps;
+  e->proposed += (unsigned long long)e->n * (unsigned long long)n_sweeps * (magphase ? 2ull : 1ull);
+  return ME_OK;
+}
+
+int me_step(me_engine *e, int32_t n_sweeps) { return me_step_kind(e, ME_STEP_ALL, n_sweeps); }
+
+int me_step_kind(me_engine *e, int32_t kind, int32_t n_sweeps) {
+  if (!e) return ME_ERR_INVALID;
+  if (n_sweeps <= 0) return fail(e, ME_ERR_INVALID, "n_sweeps must be positive");
+  ME_HIP(e, hipSetDevice(e->device));
+  return launch_step_kind(e, kind, n_sweeps, nullptr, nullptr);
+}
+
+int me_step_injected(me_engine *e, int32_t kind, int32_t n_sweeps, const double *normals, const double *uniforms) {
   if (!e || !normals || !uniforms) return ME_ERR_INVALID;
   if (n_sweeps <= 0) return fail(e, ME_ERR_INVALID, "n_sweeps must be positive");
   if (e->dtype != ME_F64) return fail(e, ME_ERR_UNSUPPORTED, "injected-stream replay is compiled for float64 engines only");
   ME_HIP(e, hipSetDevice(e->device));
-  const size_t n = (size_t)e->n, d = (size_t)e->d, k = (size_t)n_sweeps;
-  std::vector<double> zn(k * d * n), un(k * n);
+  // per chain and sweep: Gaussian kinds take D normals + 1 uniform; the magnitude-phase pair nc normals + nc+2 uniforms
+  const bool magphase = kind == ME_STEP_COMPLEX_MAGNITUDE_PHASE;
+  const size_t n = (size_t)e->n, k = (size_t)n_sweeps;
+  const size_t nz = magphase ? (size_t)e->nc : (size_t)e->d, nu = magphase ? (size_t)e->nc + 2 : 1;
+  std::vector<double> zn(k * nz * n), un(k * nu * n);
   for (size_t s = 0; s < k; ++s)
     for (size_t c = 0; c < n; ++c) {
-      for (size_t j = 0; j < d; ++j) zn[(s * d + j) * n + c] = normals[(s * n + c) * d + j];
-      un[s * n + c] = uniforms[s * n + c];
+      for (size_t j = 0; j < nz; ++j) zn[(s * nz + j) * n + c] = normals[(s * n + c) * nz + j];
+      for (size_t j = 0; j < nu; ++j) un[(s * nu + j) * n + c] = uniforms[(s * n + c) * nu + j];
     }
   double *zd = nullptr, *ud = nullptr;
   ME_HIP(e, hipMalloc((void **)&zd, zn.size() * sizeof(double)));
@@ -516,17 +579,8 @@ int me_step_injected(me_engine *e, int32_t n_sweeps, const double *normals, cons
       hipMemcpy(ud, un.data(), un.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
     rc = fail(e, ME_ERR_HIP, "upload of the injected streams failed");
   } else {
-    StepLaunch l;
-    fill_step_launch(e, l, n_sweeps);
-    l.inj_normals = zd;
-    l.inj_uniforms = ud;
-    herr = e->ks->step(l, e->stream);
-    if (herr == hipSuccess) herr = hipStreamSynchronize(e->stream);
-    if (herr != hipSuccess) rc = fail(e, ME_ERR_HIP, std::string("injected step: ") + hipGetErrorString(herr));
-    else {
-      e->step_index += (unsigned long long)n_sweeps;
-      e->proposed += (unsigned long long)e->n * (unsigned long long)n_sweeps;
-    }
+    rc = launch_step_kind(e, kind, n_sweeps, zd, ud);
+    if (rc == ME_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(e, ME_ERR_HIP, "injected step failed");
   }
   (void)hipFree(zd);
   (void)hipFree(ud);
@@ -548,6 +602,7 @@ int me_measure(me_engine *e) {
   l.n = e->n;
   l.measure_count = e->measure_count;
   l.update_cov = (e->measure_count > 50 && e->cov) ? 1 : 0;   // :389, :396
+  l.split_widths = (e->width_rows == 3 && !e->widths_synced) ? 1 : 0;
   l.write_factor = (l.update_cov && e->cov_mode == ME_COV_REFERENCE) ? 1 : 0;
   l.grid_blocks = e->grid_blocks;
   ME_HIP(e, e->ks->measure(l, e->stream));
@@ -588,6 +643,8 @@ int me_get(me_engine *e, int32_t field, int64_t chain_begin, int64_t n_chains, d
     for (int r = 0; r < comps; ++r)
       for (int64_t c = 0; c < n_chains; ++c) dst[c * comps + r] = t[(size_t)r * n_chains + c];
   }
+  if (field == ME_FIELD_WIDTH && e->width_rows == 3 && e->widths_synced)
+    for (int64_t c = 0; c < n_chains; ++c) dst[c * 3 + 1] = dst[c * 3 + 2] = dst[c * 3];
   return check_status(e);
 }
 
@@ -616,6 +673,10 @@ int me_set(me_engine *e, int32_t field, int64_t chain_begin, int64_t n_chains, c
                              hipMemcpyHostToDevice, e->stream));
   ME_HIP(e, hipStreamSynchronize(e->stream));
   if (field == ME_FIELD_FACTOR) e->cov_kind = CK_PER_CHAIN;
+  if (field == ME_FIELD_WIDTH && e->width_rows == 3) {
+    if (chain_begin != 0 || n_chains != e->n) return fail(e, ME_ERR_INVALID, "widths of a mixed engine must be set for all chains at once");
+    e->widths_synced = false;
+  }
   return ME_OK;
 }
 
@@ -729,6 +790,7 @@ int me_time_steps(me_engine *e, int32_t n_launches, int32_t n_sweeps, float *ela
     }
     e->step_index += (unsigned long long)n_sweeps;
     e->proposed += (unsigned long long)e->n * (unsigned long long)n_sweeps;
+    e->widths_synced = true;
   }
   ME_HIP(e, hipEventRecord(stop, e->stream));
   ME_HIP(e, hipEventSynchronize(stop));

@@ -222,6 +222,7 @@ struct StepArgs {
   unsigned long long chain_offset, step_index;
   uint32_t seed_lo, seed_hi;
   int n_sweeps, reject_kind;
+  int split_widths;   // mixed engines: group widths (rows 1, 2) differ from the shared width (row 0)
   R reject_bound, temp, inv_temp_log2e, ratio, p, damping, up, down;
 };
 
@@ -244,18 +245,28 @@ __host__ __device__ constexpr int cdiag(int pr, int i) { return pr + i * i + 2 *
 #else
 #define ME_STEP_BOUNDS __launch_bounds__(kBlockThreads)
 #endif
-template <typename R, int NR, int NC, class Energy, int CK, bool INJECT = false>
+// GROUP selects which coordinates move: GROUP_ALL = step_all (:241-259); GROUP_REAL / GROUP_COMPLEX = a mixed
+// engine's step_real_group / step_complex_group called directly (:209-239).  The word layout of a step is the same
+// in all three (normal i belongs to coordinate i); draws of the resting group are dead code and are eliminated.
+// Widths of mixed engines are three rows [sampling_width, real group, complex group] (:93-99, :429-456):
+// step_all adapts row 0 and mirrors it into the group widths (:436-437), a group step adapts only its own row.
+
+template <typename R, int NR, int NC, class Energy, int CK, bool INJECT = false, int GROUP = GROUP_ALL>
 __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   constexpr int D = NR + 2 * NC;
   constexpr int PR = NR * (NR + 1) / 2;
   constexpr int NW = 2 * ((D + 1) / 2);     // words consumed by the Box-Muller pairs
   constexpr int NBLK = (NW + 1 + 3) / 4;    // Philox blocks per step (word NW is the accept uniform)
+  constexpr bool MIXED = NR > 0 && NC > 0;
+  constexpr bool MOVE_REAL = NR > 0 && GROUP != GROUP_COMPLEX;
+  constexpr bool MOVE_COMPLEX = NC > 0 && GROUP != GROUP_REAL;
+  static_assert(GROUP == GROUP_ALL || MIXED, "group-wise kernels exist for mixed engines only");
   using N_ = Num<R>;
 
   unsigned int wave_accepted = 0;
   bool bad_energy = false, bad_width = false;
   const long long stride = (long long)gridDim.x * kBlockThreads;
-  const Field<R> fx(a.x, a.n, D), fe(a.energy, a.n, 1), fw(a.width, a.n, 1);
+  const Field<R> fx(a.x, a.n, D), fe(a.energy, a.n, 1), fw(a.width, a.n, MIXED ? 3 : 1);
   const Field<R> ffac(a.factor, a.n, CK == CK_PER_CHAIN ? NR * (NR + 1) / 2 + NC * NC : 0);
   for (long long c = (long long)blockIdx.x * kBlockThreads + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
@@ -263,7 +274,15 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
 #pragma unroll
     for (int d = 0; d < D; ++d) x[d] = fx.load(d, coff);
     R e = fe.load(0, coff);
-    R w = fw.load(0, coff);
+    // w: the width this launch adapts; w_r / w_c: the widths the real / complex proposals use
+    R w = fw.load(MIXED ? GROUP : 0, coff);
+    R w_r = w, w_c = w;
+    if constexpr (MIXED && GROUP == GROUP_ALL) {
+      if (a.split_widths) {   // a group step ran since the last step_all: the group widths differ from row 0
+        w_r = fw.load(GROUP_REAL, coff);
+        w_c = fw.load(GROUP_COMPLEX, coff);
+      }
+    }
     const unsigned long long gid = a.chain_offset + (unsigned long long)c;
     // CK_PER_CHAIN reads element k at factor[k*n + c] (coalesced); CK_SHARED reads factor[k] (wave-uniform)
     auto fac = [&](int k) -> R {
@@ -299,40 +318,50 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
         u = N_::unit(words[NW]);
       }
 
-      // ---- proposal: x' = x + w L_r g_r ; z' = z + w L_c (g_re + i g_im)/sqrt2   (:261-302)
+      // ---- proposal: x' = x + w_r L_r g_r ; z' = z + w_c L_c (g_re + i g_im)/sqrt2   (:261-302)
       R xp[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) xp[d] = x[d];
       if constexpr (CK == CK_IDENTITY) {
+        if constexpr (MOVE_REAL) {
 #pragma unroll
-        for (int i = 0; i < NR; ++i) xp[i] = x[i] + w * g[i];
+          for (int i = 0; i < NR; ++i) xp[i] = x[i] + w_r * g[i];
+        }
+        if constexpr (MOVE_COMPLEX) {
 #pragma unroll
-        for (int j = 0; j < NC; ++j) {
-          xp[NR + j] = x[NR + j] + w * (g[NR + j] * R(0.70710678118654752440));
-          xp[NR + NC + j] = x[NR + NC + j] + w * (g[NR + NC + j] * R(0.70710678118654752440));
+          for (int j = 0; j < NC; ++j) {
+            xp[NR + j] = x[NR + j] + w_c * (g[NR + j] * R(0.70710678118654752440));
+            xp[NR + NC + j] = x[NR + NC + j] + w_c * (g[NR + NC + j] * R(0.70710678118654752440));
+          }
         }
       } else {
+        if constexpr (MOVE_REAL) {
 #pragma unroll
-        for (int i = 0; i < NR; ++i) {
-          R acc = 0;
+          for (int i = 0; i < NR; ++i) {
+            R acc = 0;
 #pragma unroll
-          for (int j = 0; j <= i; ++j) acc += fac(tri(i, j)) * g[j];
-          xp[i] = x[i] + w * acc;
-        }
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-          R are = 0, aim = 0;
-#pragma unroll
-          for (int j = 0; j < i; ++j) {
-            const R lre = fac(cre(PR, i, j));
-            const R lim = fac(cim(PR, i, j));
-            const R wre = g[NR + j] * R(0.70710678118654752440), wim = g[NR + NC + j] * R(0.70710678118654752440);
-            are += lre * wre - lim * wim;
-            aim += lre * wim + lim * wre;
+            for (int j = 0; j <= i; ++j) acc += fac(tri(i, j)) * g[j];
+            xp[i] = x[i] + w_r * acc;
           }
-          const R ld = fac(cdiag(PR, i));
-          are += ld * (g[NR + i] * R(0.70710678118654752440));
-          aim += ld * (g[NR + NC + i] * R(0.70710678118654752440));
-          xp[NR + i] = x[NR + i] + w * are;
-          xp[NR + NC + i] = x[NR + NC + i] + w * aim;
+        }
+        if constexpr (MOVE_COMPLEX) {
+#pragma unroll
+          for (int i = 0; i < NC; ++i) {
+            R are = 0, aim = 0;
+#pragma unroll
+            for (int j = 0; j < i; ++j) {
+              const R lre = fac(cre(PR, i, j));
+              const R lim = fac(cim(PR, i, j));
+              const R wre = g[NR + j] * R(0.70710678118654752440), wim = g[NR + NC + j] * R(0.70710678118654752440);
+              are += lre * wre - lim * wim;
+              aim += lre * wim + lim * wre;
+            }
+            const R ld = fac(cdiag(PR, i));
+            are += ld * (g[NR + i] * R(0.70710678118654752440));
+            aim += ld * (g[NR + NC + i] * R(0.70710678118654752440));
+            xp[NR + i] = x[NR + i] + w_c * are;
+            xp[NR + NC + i] = x[NR + NC + i] + w_c * aim;
+          }
         }
       }
 
@@ -348,15 +377,18 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
 #pragma unroll
       for (int d = 0; d < D; ++d) x[d] = accept ? xp[d] : x[d];
       e = accept ? e_new : e;
-      // ---- Robbins-Monro width update (:429-456)
+      // ---- Robbins-Monro width update (:429-456); step_all of a mixed engine mirrors it into both groups (:436-437)
       w = N_::adapt(w, accept, a.ratio, a.p, a.damping, a.up, a.down);
+      if constexpr (GROUP == GROUP_ALL) w_r = w_c = w;
+      else if constexpr (GROUP == GROUP_REAL) w_r = w;
+      else w_c = w;
       wave_accepted += (unsigned int)__popcll(__ballot(accept));
     }
     bad_width |= !(w > R(0));
 #pragma unroll
     for (int d = 0; d < D; ++d) fx.store(d, coff, x[d]);
     fe.store(0, coff, e);
-    fw.store(0, coff, w);
+    fw.store(MIXED ? GROUP : 0, coff, w);   // after a mixed step_all rows 1, 2 are implied equal to row 0 (host flag)
   }
   // acceptance tracking: ballot + popcount per sweep, then ONE plain read-modify-write of the wavefront's own
   // slot per launch.  (Same-address atomics serialise at ~12 ns each at the memory side: 2^14 wavefronts adding
@@ -394,7 +426,7 @@ struct MeasureArgs {
   R keep;      // (i-1)/i
   R inv_i;     // 1/i
   R cov_keep;  // (i-2)/(i-1)
-  int update_cov, write_factor;
+  int update_cov, write_factor, split_widths;
 };
 
 // Running mean, Haario-type covariance recursion with the reference's undivided epsilon term (quirk Q1),
@@ -412,7 +444,7 @@ __global__ void __launch_bounds__(kBlockThreads) k_measure(MeasureArgs<R> a) {
   using N_ = Num<R>;
   bool bad_pivot = false;
   const long long stride = (long long)gridDim.x * kBlockThreads;
-  const Field<R> fx(a.x, a.n, D), fw(a.width, a.n, 1), fmean(a.mean, a.n, D), fobs(a.obs_mean, a.n, NOBS);
+  const Field<R> fx(a.x, a.n, D), fw(a.width, a.n, (NR > 0 && NC > 0) ? 3 : 1), fmean(a.mean, a.n, D), fobs(a.obs_mean, a.n, NOBS);
   const Field<R> fcov(a.cov, a.n, PER_CHAIN_COV ? P : 0), ffac(a.factor, a.n, PER_CHAIN_COV ? P : 0);
   for (long long c = (long long)blockIdx.x * kBlockThreads + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
@@ -436,8 +468,12 @@ __global__ void __launch_bounds__(kBlockThreads) k_measure(MeasureArgs<R> a) {
     }
     if constexpr (PER_CHAIN_COV) {
       if (a.update_cov) {
-        const R w = fw.load(0, coff);
-        const R eps = w * w * a.inv_i;   // :418, :425 -- the shared width in mixed engines (:436-437)
+        // :418, :425 -- each block uses its own group's width; they coincide unless group steps made them differ
+        constexpr bool MIXED = NR > 0 && NC > 0;
+        const R w_real = fw.load((MIXED && a.split_widths) ? 1 : 0, coff);
+        const R w_cplx = fw.load((MIXED && a.split_widths) ? 2 : 0, coff);
+        const R eps = w_real * w_real * a.inv_i;
+        const R eps_c = w_cplx * w_cplx * a.inv_i;
         R m[P];
 #pragma unroll
         for (int i = 0; i < NR; ++i)
@@ -464,7 +500,7 @@ __global__ void __launch_bounds__(kBlockThreads) k_measure(MeasureArgs<R> a) {
             m[ki] = -vi;   // the proposals use conj(K) (quirk Q3, :292-298)
           }
           const int kd = cdiag(PR, i);
-          const R vd = fcov.load(kd, coff) * a.cov_keep + (ai * ai + bi * bi) * a.inv_i + eps;
+          const R vd = fcov.load(kd, coff) * a.cov_keep + (ai * ai + bi * bi) * a.inv_i + eps_c;
           fcov.store(kd, coff, vd);
           m[kd] = vd;
         }

@@ -13,6 +13,9 @@ namespace me {
 // How the step kernel obtains the proposal shape.
 enum CovKind { CK_IDENTITY = 0, CK_SHARED = 1, CK_PER_CHAIN = 2 };
 
+// which coordinates a step launch moves (row index of the adapting width in mixed engines)
+enum StepGroup { GROUP_ALL = 0, GROUP_REAL = 1, GROUP_COMPLEX = 2 };
+
 enum StatusBits : uint32_t {
   ST_NONFINITE_ENERGY = 1u,  // a proposed state that was not wall-rejected had a non-finite energy
   ST_BAD_PIVOT = 2u,         // Cholesky pivot <= 0 while refreshing a proposal factor
@@ -37,6 +40,9 @@ struct StepLaunch {
   long long n;
   unsigned long long chain_offset, step_index, seed;
   int n_sweeps, energy_kind, cov_kind, reject_kind, grid_blocks;
+  int group;          // StepGroup: 0 = all (step_all), 1 = real group, 2 = complex group (mixed engines)
+  int split_widths;   // mixed engines: rows 1, 2 of the width field differ from row 0
+  const void *cov;    // per-chain covariance field (magnitude-phase sampler reads its diagonal)
   double reject_bound, temp, ratio, target_acceptance, damping;
 };
 
@@ -46,6 +52,7 @@ struct MeasureLaunch {
   long long n;
   unsigned long long measure_count;  // value AFTER the increment (metropolis_engine.py:343)
   int update_cov;                    // measure_count > 50 (:389, :396)
+  int split_widths;                  // see StepLaunch
   int write_factor;                  // refresh the per-chain Cholesky factors
   int grid_blocks;
 };
@@ -66,6 +73,7 @@ struct KernelSet {
   bool per_chain_cov;  // measure can refresh per-chain factors / step can read them
   bool (*has_energy)(int energy_kind);
   hipError_t (*step)(const StepLaunch &, hipStream_t);
+  hipError_t (*magphase)(const StepLaunch &, hipStream_t);   // nullptr: no complex group / no per-chain covariance
   hipError_t (*measure)(const MeasureLaunch &, hipStream_t);
   hipError_t (*init_energy)(const EnergyLaunch &, hipStream_t);
 };

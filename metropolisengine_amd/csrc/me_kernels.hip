@@ -6,6 +6,7 @@
 
 #include "me_device.h"
 #include "me_dense_mfma.h"
+#include "me_magphase.h"
 
 // User-energy plugin mode: -DME_USER_SOURCE='"file"' -DME_USER_NAME='"name"' compiles the SAME kernels around a
 // user-written device function (include/metropolis_user_energy.h) into a plugin library that registers itself.
@@ -96,6 +97,7 @@ StepArgs<R> typed(const StepLaunch &l) {
   a.seed_hi = (uint32_t)(l.seed >> 32);
   a.n_sweeps = l.n_sweeps;
   a.reject_kind = l.reject_kind;
+  a.split_widths = l.split_widths;
   a.reject_bound = (R)l.reject_bound;
   a.temp = (R)l.temp;
   a.inv_temp_log2e = l.temp > 0 ? (R)(1.4426950408889634 / l.temp) : (R)0;
@@ -107,25 +109,39 @@ StepArgs<R> typed(const StepLaunch &l) {
   return a;
 }
 
+template <typename R, class Energy, bool INJECT, int GROUP>
+hipError_t launch_step_cov(const StepLaunch &l, const StepArgs<R> &a, const Energy &en, dim3 grid, dim3 block,
+                           hipStream_t stream) {
+  switch (l.cov_kind) {
+    case CK_IDENTITY: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_IDENTITY, INJECT, GROUP>), grid, block, 0, stream, a, en); break;
+    case CK_SHARED: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_SHARED, INJECT, GROUP>), grid, block, 0, stream, a, en); break;
+#if ME_PER_CHAIN
+    case CK_PER_CHAIN: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_PER_CHAIN, INJECT, GROUP>), grid, block, 0, stream, a, en); break;
+#endif
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+template <typename R, class Energy, bool INJECT>
+hipError_t launch_step_group(const StepLaunch &l, const StepArgs<R> &a, const Energy &en, dim3 grid, dim3 block,
+                             hipStream_t stream) {
+  if (l.group == GROUP_ALL) return launch_step_cov<R, Energy, INJECT, GROUP_ALL>(l, a, en, grid, block, stream);
+  if constexpr (NR > 0 && NC > 0) {   // group-wise stepping exists for mixed engines (pure engines alias step_all)
+    if (l.group == GROUP_REAL) return launch_step_cov<R, Energy, INJECT, GROUP_REAL>(l, a, en, grid, block, stream);
+    if (l.group == GROUP_COMPLEX) return launch_step_cov<R, Energy, INJECT, GROUP_COMPLEX>(l, a, en, grid, block, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
 template <typename R, class Energy>
 hipError_t step_with(const StepLaunch &l, const Energy &en, hipStream_t stream) {
   const StepArgs<R> a = typed<R>(l);
   const dim3 grid(grid_for(l.n, l.grid_blocks)), block(kBlockThreads);
   if (l.inj_normals) {
     // injected-stream replay: float64 only (it exists to check trajectories against the float64 reference)
-    if constexpr (std::is_same<R, double>::value) {
-      switch (l.cov_kind) {
-        case CK_IDENTITY: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_IDENTITY, true>), grid, block, 0, stream, a, en); break;
-        case CK_SHARED: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_SHARED, true>), grid, block, 0, stream, a, en); break;
-#if ME_PER_CHAIN
-        case CK_PER_CHAIN: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_PER_CHAIN, true>), grid, block, 0, stream, a, en); break;
-#endif
-        default: return hipErrorInvalidValue;
-      }
-      return hipGetLastError();
-    } else {
-      return hipErrorNotSupported;
-    }
+    if constexpr (std::is_same<R, double>::value) return launch_step_group<R, Energy, true>(l, a, en, grid, block, stream);
+    else return hipErrorNotSupported;
   }
 #if ME_DENSE && !defined(ME_USER_SOURCE)
   // BASELINE config 4: 64 real parameters, dense quadratic form, fp32 -> matrix-core kernel (me_dense_mfma.h)
@@ -140,15 +156,29 @@ hipError_t step_with(const StepLaunch &l, const Energy &en, hipStream_t stream) 
     return hipErrorInvalidValue;
   } else
 #endif
-  switch (l.cov_kind) {
-    case CK_IDENTITY: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_IDENTITY>), grid, block, 0, stream, a, en); break;
-    case CK_SHARED: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_SHARED>), grid, block, 0, stream, a, en); break;
+    return launch_step_group<R, Energy, false>(l, a, en, grid, block, stream);
+}
+
+// the magnitude-phase complex sampler (me_magphase.h); a.factor carries the covariance field
+template <typename R, class Energy>
+hipError_t magphase_with(const StepLaunch &l, const Energy &en, hipStream_t stream) {
 #if ME_PER_CHAIN
-    case CK_PER_CHAIN: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_PER_CHAIN>), grid, block, 0, stream, a, en); break;
-#endif
-    default: return hipErrorInvalidValue;
+  if constexpr (NC > 0) {
+    StepArgs<R> a = typed<R>(l);
+    a.factor = (const R *)l.cov;
+    const dim3 grid(grid_for(l.n, l.grid_blocks)), block(kBlockThreads);
+    if (l.inj_normals) {
+      if constexpr (std::is_same<R, double>::value)
+        hipLaunchKernelGGL((k_step_magphase<R, NR, NC, Energy, true>), grid, block, 0, stream, a, en);
+      else
+        return hipErrorNotSupported;
+    } else {
+      hipLaunchKernelGGL((k_step_magphase<R, NR, NC, Energy, false>), grid, block, 0, stream, a, en);
+    }
+    return hipGetLastError();
   }
-  return hipGetLastError();
+#endif
+  return hipErrorNotSupported;
 }
 
 // Build the by-value energy functor from the coefficient list and hand it to `f`.
@@ -215,6 +245,12 @@ hipError_t step(const StepLaunch &l, hipStream_t stream) {
 }
 
 template <typename R>
+hipError_t magphase(const StepLaunch &l, hipStream_t stream) {
+  return with_energy<R>(l.energy_kind, l.coef_host, l.n_coef, l.coef_device,
+                        [&](const auto &en) { return magphase_with<R>(l, en, stream); });
+}
+
+template <typename R>
 hipError_t init_energy(const EnergyLaunch &l, hipStream_t stream) {
   return with_energy<R>(l.energy_kind, l.coef_host, l.n_coef, l.coef_device, [&](const auto &en) {
     using Energy = std::decay_t<decltype(en)>;
@@ -240,6 +276,7 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
   a.inv_i = (R)(1.0 / i);
   a.cov_keep = (R)((i - 2.0) / (i - 1.0));
   a.update_cov = l.update_cov;
+  a.split_widths = l.split_widths;
   a.write_factor = l.write_factor;
   hipLaunchKernelGGL((k_measure<R, NR, NC, ME_PER_CHAIN != 0>), dim3(grid_for(l.n, l.grid_blocks)), dim3(kBlockThreads), 0,
                      stream, a);
@@ -251,9 +288,10 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
 #else
 #define ME_SET_NAME nullptr
 #endif
-const KernelSet kSetF32 = {ME_SET_NAME, ME_F32, NR, NC, ME_PER_CHAIN != 0, has_energy, step<float>, measure<float>, init_energy<float>};
-const KernelSet kSetF64 = {ME_SET_NAME, ME_F64, NR, NC, ME_PER_CHAIN != 0, has_energy, step<double>, measure<double>,
-                           init_energy<double>};
+const KernelSet kSetF32 = {ME_SET_NAME, ME_F32, NR, NC, ME_PER_CHAIN != 0, has_energy, step<float>,
+                           (NC > 0 && ME_PER_CHAIN) ? magphase<float> : nullptr, measure<float>, init_energy<float>};
+const KernelSet kSetF64 = {ME_SET_NAME, ME_F64, NR, NC, ME_PER_CHAIN != 0, has_energy, step<double>,
+                           (NC > 0 && ME_PER_CHAIN) ? magphase<double> : nullptr, measure<double>, init_energy<double>};
 
 struct Registrar {
   Registrar() {

@@ -77,10 +77,7 @@ class MetropolisEngine:
                 "kernel and this engine has no CPU fallback")
         if reject_condition is not None and not isinstance(reject_condition, RejectSpec):
             raise TypeError("reject_condition must be a metropolisengine_amd.energy.RejectSpec or None")
-        if complex_sample_method == "magnitude-phase":
-            raise NotImplementedError("complex_sample_method='magnitude-phase' (metropolis_engine.py:168-207) is not "
-                                      "built yet; only the default multivariate-gaussian sampler runs on the GPU")
-        elif complex_sample_method != "multivariate-gaussian":
+        if complex_sample_method not in ("magnitude-phase", "multivariate-gaussian"):
             print("complex_sample_method", complex_sample_method, "not recognized")       # :131-133
             print("defaulting to multivariate-gaussian")
         if temp is None or not temp >= 0:
@@ -105,6 +102,9 @@ class MetropolisEngine:
         self.temp = temp
         self.target_acceptance = target_acceptance
         self._initial_width = float(sampling_width)
+        # "magnitude-phase" swaps step_complex_group only; step_all keeps the Gaussian sampler (:129-130, quirk Q9)
+        self.complex_sample_method = ("magnitude-phase" if complex_sample_method == "magnitude-phase"
+                                      else "multivariate-gaussian")
         self._energy_spec = energy_functions
         self._reject_spec = reject_condition
         if params_names:
@@ -200,28 +200,41 @@ class MetropolisEngine:
             return took if n_sweeps == 1 else None
         return None
 
-    def step_injected(self, normals, uniforms):
-        """Test hook (float64 engines): step with caller-supplied draws, ``normals[sweep, chain, D]`` and
-        ``uniforms[sweep, chain]``, instead of the Philox stream (see ``me_step_injected``)."""
+    def step_injected(self, normals, uniforms, kind=_capi.STEP_ALL):
+        """Test hook (float64 engines): step with caller-supplied draws instead of the Philox stream
+        (``me_step_injected``): ``normals[sweep, chain, D]`` and ``uniforms[sweep, chain]`` for the Gaussian kinds,
+        ``normals[sweep, chain, nc]`` and ``uniforms[sweep, chain, nc + 2]`` for the magnitude-phase pair."""
         normals = np.ascontiguousarray(normals, dtype=np.float64)
         uniforms = np.ascontiguousarray(uniforms, dtype=np.float64)
-        d = self.num_real_params + 2 * self.num_complex_params
-        if normals.ndim != 3 or normals.shape[1:] != (self.n_chains, d) or uniforms.shape != normals.shape[:2]:
-            raise ValueError("normals must be [sweeps, n_chains, D] and uniforms [sweeps, n_chains]")
-        self._check(self._lib.me_step_injected(self._handle, normals.shape[0], _as_double_ptr(normals),
+        nc = self.num_complex_params
+        magphase = kind == _capi.STEP_COMPLEX_MAGNITUDE_PHASE
+        nz = nc if magphase else self.num_real_params + 2 * nc
+        want_u = normals.shape[:2] + ((nc + 2,) if magphase else ())
+        if normals.ndim != 3 or normals.shape[1:] != (self.n_chains, nz) or uniforms.shape != want_u:
+            raise ValueError("injected streams have the wrong shape for this step kind")
+        self._check(self._lib.me_step_injected(self._handle, int(kind), normals.shape[0], _as_double_ptr(normals),
                                                _as_double_ptr(uniforms)))
 
+    def _step_kind(self, kind, n_sweeps):
+        before = self.accept_stats()[0] if self.n_chains == 1 else 0
+        self._check(self._lib.me_step_kind(self._handle, int(kind), int(n_sweeps)))
+        if self.n_chains == 1 and n_sweeps == 1 and kind != _capi.STEP_COMPLEX_MAGNITUDE_PHASE:
+            accepted = self.accept_stats()[0]
+            self._last_accepted = accepted
+            return accepted > before
+        return None                                   # the magnitude-phase pair returns None (:175-176)
+
     def step_real_group(self, n_sweeps=1):
-        if self.num_complex_params:
-            raise NotImplementedError("group-wise stepping of mixed engines (metropolis_engine.py:225-239 with "
-                                      "partial energy terms) is not built yet; use step_all()")
-        return self.step_all(n_sweeps)                                                   # :56
+        """metropolis_engine.py:225-239: only the real parameters move, only the real width adapts.  On pure-real
+        engines this IS step_all (:56)."""
+        return self._step_kind(_capi.STEP_REAL_GROUP, n_sweeps)
 
     def step_complex_group(self, n_sweeps=1):
-        if self.num_real_params:
-            raise NotImplementedError("group-wise stepping of mixed engines (metropolis_engine.py:209-223 with "
-                                      "partial energy terms) is not built yet; use step_all()")
-        return self.step_all(n_sweeps)                                                   # :46
+        """metropolis_engine.py:209-223, or the magnitude-phase pair (:168-207) when the engine was built with
+        ``complex_sample_method="magnitude-phase"``."""
+        if self.complex_sample_method == "magnitude-phase":
+            return self._step_kind(_capi.STEP_COMPLEX_MAGNITUDE_PHASE, n_sweeps)
+        return self._step_kind(_capi.STEP_COMPLEX_GROUP, n_sweeps)
 
     def measure(self):
         """Update running means, covariances (once measure_step_counter > 50) and observables (:342-427)."""
@@ -303,22 +316,23 @@ class MetropolisEngine:
     def observables_mean(self):
         return self._squeeze(self._get(_capi.FIELD_OBS_MEAN))
 
-    def _width(self):
-        w = self._get(_capi.FIELD_WIDTH)[:, 0]
+    def _width(self, row):
+        w = self._get(_capi.FIELD_WIDTH)       # [n, 1], or [n, 3] = (sampling_width, real, complex) for mixed engines
+        w = w[:, row if w.shape[1] == 3 else 0]
         return float(w[0]) if self.n_chains == 1 else w
 
     @property
     def sampling_width(self):
-        return self._width()
+        return self._width(0)
 
     @property
     def real_group_sampling_width(self):
         # pure-complex engines never touch the real width (:449-456)
-        return self._width() if self.num_real_params else self._initial_width
+        return self._width(1) if self.num_real_params else self._initial_width
 
     @property
     def complex_group_sampling_width(self):
-        return self._width() if self.num_complex_params else self._initial_width
+        return self._width(2) if self.num_complex_params else self._initial_width
 
     @property
     def energy_total(self):

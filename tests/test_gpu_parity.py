@@ -126,7 +126,7 @@ def test_reference_golden_trajectory_on_gpu(name, golden_dir):
     t = 0
     accepted = 0
     for k in range(spec["n_measures"]):
-        eng.step_injected(gold["normals"][t:t + spm, None, :], gold["uniforms"][t:t + spm, None])
+        eng.step_injected(gold["normals"][t:t + spm, None, :], gold["uniforms"][t:t + spm, :1])
         t += spm
         eng.measure()
         accepted_now = eng.accept_stats()[0]
