@@ -172,6 +172,14 @@ int me_pooled_moments_device(me_engine *engine, void *device_out, int64_t n_doub
 /* Install the shared proposal factor of ME_COV_POOLED: packed like ME_FIELD_FACTOR, [P] doubles. */
 int me_set_shared_factor(me_engine *engine, const double *packed_factor, int64_t n_doubles);
 
+/* Time series (metropolis_engine.py:350-356, :466-479): every me_measure appends one row per traced chain
+ * (chains t*stride, t < n_traced) to a device-side series; me_trace_get returns it as doubles
+ * [row][column][traced chain] with columns {params (D), energy, widths (1, or 3 for mixed engines)}.
+ * n_traced = 0 switches recording off (the default). */
+int me_trace_enable(me_engine *engine, int64_t n_traced, int64_t stride);
+int me_trace_shape(me_engine *engine, int64_t *rows, int64_t *cols, int64_t *n_traced);
+int me_trace_get(me_engine *engine, double *dst, int64_t n_doubles);
+
 int me_sync(me_engine *engine);
 /* Use an existing HIP stream (hipStream_t passed as void*) instead of the engine's own. */
 int me_set_stream(me_engine *engine, void *hip_stream);

@@ -59,6 +59,10 @@ SYMBOLS = {
     "me_pooled_moments": (ctypes.c_int, [_H, _dp, ctypes.c_int64]),
     "me_pooled_moments_device": (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.c_int64]),
     "me_set_shared_factor": (ctypes.c_int, [_H, _dp, ctypes.c_int64]),
+    "me_trace_enable": (ctypes.c_int, [_H, ctypes.c_int64, ctypes.c_int64]),
+    "me_trace_shape": (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                      ctypes.POINTER(ctypes.c_int64)]),
+    "me_trace_get": (ctypes.c_int, [_H, _dp, ctypes.c_int64]),
     "me_sync": (ctypes.c_int, [_H]),
     "me_set_stream": (ctypes.c_int, [_H, ctypes.c_void_p]),
     "me_time_steps": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]),

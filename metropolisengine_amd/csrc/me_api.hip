@@ -126,6 +126,9 @@ struct me_engine {
   bool widths_synced = true;    // mixed engines: rows 1, 2 are implied equal to row 0 (state after a step_all)
   unsigned int *status = nullptr;
   double *pool_dev = nullptr;
+  // time-series trace of a few chains (the reference's per-measure appends, :350-356)
+  double *trace_dev = nullptr;
+  long long trace_chains = 0, trace_stride = 1, trace_rows = 0, trace_capacity = 0;
   std::string err;
 };
 
@@ -248,7 +251,7 @@ void release(me_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   void *bufs[] = {e->x, e->energy, e->width, e->mean, e->cov, e->obs_mean, e->factor, e->shared_factor, e->shared_full,
-                  e->coef_dev, e->row_dev, e->accept_slots, e->accept_total, e->status, e->pool_dev};
+                  e->coef_dev, e->row_dev, e->accept_slots, e->accept_total, e->status, e->pool_dev, e->trace_dev};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -607,6 +610,66 @@ int me_measure(me_engine *e) {
   l.grid_blocks = e->grid_blocks;
   ME_HIP(e, e->ks->measure(l, e->stream));
   if (l.write_factor) e->cov_kind = CK_PER_CHAIN;
+  if (e->trace_chains > 0) {
+    const long long cols = e->d + 1 + e->width_rows;
+    if (e->trace_rows == e->trace_capacity) {   // grow the device-side series (doubling)
+      const long long cap = e->trace_capacity ? 2 * e->trace_capacity : 1024;
+      double *bigger = nullptr;
+      ME_HIP(e, hipMalloc((void **)&bigger, sizeof(double) * (size_t)(cap * cols * e->trace_chains)));
+      if (e->trace_dev) {
+        ME_HIP(e, hipMemcpyAsync(bigger, e->trace_dev, sizeof(double) * (size_t)(e->trace_rows * cols * e->trace_chains),
+                                 hipMemcpyDeviceToDevice, e->stream));
+        ME_HIP(e, hipStreamSynchronize(e->stream));
+        (void)hipFree(e->trace_dev);
+      }
+      e->trace_dev = bigger;
+      e->trace_capacity = cap;
+    }
+    // widths: a synced mixed engine keeps only row 0 current; mirror it so that the series reads like the reference's
+    const int rows_valid = (e->width_rows == 3 && e->widths_synced) ? 1 : e->width_rows;
+    ME_HIP(e, launch_trace(e->x, e->energy, e->width, e->n, e->d, rows_valid, e->dtype, e->trace_chains, e->trace_stride,
+                           e->trace_dev + e->trace_rows * cols * e->trace_chains, e->stream));
+    if (rows_valid != e->width_rows) {
+      double *row = e->trace_dev + e->trace_rows * cols * e->trace_chains + (size_t)(e->d + 1) * e->trace_chains;
+      for (int r = 1; r < 3; ++r)
+        ME_HIP(e, hipMemcpyAsync(row + (size_t)r * e->trace_chains, row, sizeof(double) * (size_t)e->trace_chains,
+                                 hipMemcpyDeviceToDevice, e->stream));
+    }
+    e->trace_rows += 1;
+  }
+  return ME_OK;
+}
+
+int me_trace_enable(me_engine *e, int64_t n_traced, int64_t stride) {
+  if (!e) return ME_ERR_INVALID;
+  if (n_traced < 0 || stride < 1 || (n_traced > 0 && (n_traced - 1) * stride >= e->n))
+    return fail(e, ME_ERR_INVALID, "traced chains out of range");
+  ME_HIP(e, hipSetDevice(e->device));
+  ME_HIP(e, hipStreamSynchronize(e->stream));
+  if (e->trace_dev) (void)hipFree(e->trace_dev);
+  e->trace_dev = nullptr;
+  e->trace_chains = n_traced;
+  e->trace_stride = stride;
+  e->trace_rows = e->trace_capacity = 0;
+  return ME_OK;
+}
+
+int me_trace_shape(me_engine *e, int64_t *rows, int64_t *cols, int64_t *n_traced) {
+  if (!e) return ME_ERR_INVALID;
+  if (rows) *rows = e->trace_rows;
+  if (cols) *cols = e->d + 1 + e->width_rows;
+  if (n_traced) *n_traced = e->trace_chains;
+  return ME_OK;
+}
+
+int me_trace_get(me_engine *e, double *dst, int64_t n_doubles) {
+  if (!e || !dst) return ME_ERR_INVALID;
+  const long long want = e->trace_rows * (e->d + 1 + e->width_rows) * e->trace_chains;
+  if (n_doubles != want) return fail(e, ME_ERR_INVALID, "wrong trace buffer length");
+  if (want == 0) return ME_OK;
+  ME_HIP(e, hipSetDevice(e->device));
+  ME_HIP(e, hipStreamSynchronize(e->stream));
+  ME_HIP(e, hipMemcpy(dst, e->trace_dev, sizeof(double) * (size_t)want, hipMemcpyDeviceToHost));
   return ME_OK;
 }
 

@@ -92,6 +92,10 @@ hipError_t launch_broadcast_rows(void *dst, const void *row_values, int rows, lo
 hipError_t launch_pool_reduce(const void *x, long long n, int n_real, int n_complex, int dtype,
                               const unsigned long long *accepted_total, double proposed, double *out_device,
                               hipStream_t stream);
+// Time-series row of the traced chains (chain t*stride, t < n_traced): out[col][t] as doubles with columns
+// [params (d) | energy | widths (width_rows)]  -- what measure() appends in the reference (:350-356).
+hipError_t launch_trace(const void *x, const void *energy, const void *width, long long n, int d, int width_rows,
+                        int dtype, long long n_traced, long long stride, double *out, hipStream_t stream);
 // total[0] = sum of slots[0 .. n_slots)
 hipError_t launch_sum_slots(const unsigned long long *slots, long long n_slots, unsigned long long *total,
                             hipStream_t stream);

@@ -66,7 +66,7 @@ class MetropolisEngine:
                  initial_complex_params=None, sampling_width=0.05, covariance_matrix_real=None,
                  covariance_matrix_complex=None, params_names=None, target_acceptance=.3, temp=0,
                  complex_sample_method="multivariate-gaussian", *, n_chains=1, seed=0, dtype="f32", device=0,
-                 chain_offset=0, cov_mode="reference"):
+                 chain_offset=0, cov_mode="reference", trace_chains=None, trace_stride=1):
         if initial_real_params is None and initial_complex_params is None:
             print("must give list containing  at least one value for initial real or complex parameters")
             raise ValueError("no initial parameters")                                    # metropolis_engine.py:37-39
@@ -173,6 +173,12 @@ class MetropolisEngine:
         _capi.check(self._lib.me_constants(handle, ctypes.byref(alpha), ctypes.byref(m), ctypes.byref(ratio)), handle)
         self.alpha, self.m, self.ratio = alpha.value, m.value, ratio.value               # :101-107
         self._last_accepted = 0
+        # time series (:31-35, :350-356): the reference records its one chain at every measure(); a single-chain engine
+        # does the same, a many-chain engine records ``trace_chains`` chains (every ``trace_stride``-th) on request
+        self.trace_chains = (1 if self.n_chains == 1 else 0) if trace_chains is None else int(trace_chains)
+        self.trace_stride = int(trace_stride)
+        if self.trace_chains:
+            _capi.check(self._lib.me_trace_enable(handle, self.trace_chains, self.trace_stride), handle)
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -425,9 +431,78 @@ class MetropolisEngine:
                                               int(state["measure_step_counter"])))
 
     # ------------------------------------------------------------------ out of scope this round
+    # ------------------------------------------------------------------ time series (:31-35, :350-356, :466-479)
+    def trace(self):
+        """Recorded series as ``[n_measures, n_traced, D + 1 + n_widths]``: params, energy, widths per measure()."""
+        rows, cols, k = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        self._check(self._lib.me_trace_shape(self._handle, ctypes.byref(rows), ctypes.byref(cols), ctypes.byref(k)))
+        out = np.empty((rows.value, cols.value, k.value), dtype=np.float64)
+        self._check(self._lib.me_trace_get(self._handle, _as_double_ptr(out), out.size))
+        return np.ascontiguousarray(out.transpose(0, 2, 1))
+
+    def _series(self, chain=0):
+        tr = self.trace()
+        if tr.shape[1] <= chain:
+            raise ValueError("chain %d is not traced (trace_chains=%d)" % (chain, self.trace_chains))
+        tr = tr[:, chain, :]
+        nr, nc = self.num_real_params, self.num_complex_params
+        d = nr + 2 * nc
+        real = tr[:, :nr]
+        cplx = tr[:, nr:nr + nc] + 1j * tr[:, nr + nc:d]
+        obs = np.concatenate((np.abs(real), np.abs(cplx), real ** 2), axis=1)
+        widths = tr[:, d + 1:]
+        w_real = widths[:, 1 if widths.shape[1] == 3 else 0] if nr else None
+        w_cplx = widths[:, 2 if widths.shape[1] == 3 else 0] if nc else None
+        return real, cplx, obs, tr[:, d], w_real, w_cplx
+
+    @property
+    def real_params_time_series(self):
+        return list(self._series()[0]) if self.num_real_params else None                  # :48
+
+    @property
+    def complex_params_time_series(self):
+        return list(self._series()[1]) if self.num_complex_params else None               # :58
+
+    @property
+    def observables_time_series(self):
+        return list(self._series()[2])
+
+    @property
+    def energy_time_series(self):
+        return {"total": list(self._series()[3])}
+
+    @property
+    def real_group_sampling_width_time_series(self):
+        return list(self._series()[4]) if self.num_real_params else None
+
+    @property
+    def complex_group_sampling_width_time_series(self):
+        return list(self._series()[5]) if self.num_complex_params else None
+
+    def time_series_frame(self, chain=0):
+        """The reference's DataFrame layout (metropolis_engine.py:466-478; column order of exampledata.csv:1) for one
+        traced chain: observables, ``<term>_energy``, real parameters, ``real_group_sampling_width``, complex
+        parameters, ``complex_group_sampling_width``."""
+        import pandas
+        real, cplx, obs, energy, w_real, w_cplx = self._series(chain)
+        nr, nc = self.num_real_params, self.num_complex_params
+        cols = {}
+        for i, name in enumerate(self.observables_names):
+            cols[name] = obs[:, i]
+        cols["total_energy"] = energy       # the reference stores one column per energy term (:468-469)
+        if nr:
+            for i in range(nr):
+                cols[self.params_names[i]] = real[:, i]
+            cols["real_group_sampling_width"] = w_real
+        if nc:
+            for i in range(nc):
+                cols[self.params_names[nr + i]] = cplx[:, i]
+            cols["complex_group_sampling_width"] = w_cplx
+        return pandas.DataFrame.from_dict(cols)
+
     def save_time_series(self):
-        raise NotImplementedError("time-series recording (metropolis_engine.py:350-356, :466-479) is host-side "
-                                  "bookkeeping outside the accelerated hot path; see DESIGN.md")
+        self.df = self.time_series_frame(0)
+        print(self.df)                                                                   # :479
 
     def save_equilibrium_stats(self, external_df=None):
         raise NotImplementedError("equilibration statistics (metropolis_engine.py:481-504) depend on pymbar and are "

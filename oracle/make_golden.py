@@ -145,7 +145,15 @@ def run_scenario(me, name, spec, stream_seed):
                                       if nc else np.zeros((0, 0), dtype=np.complex128))
             rec["observables_mean"].append(np.array(engine.observables_mean, dtype=np.float64))
         consts = np.array([engine.alpha, engine.m, engine.ratio], dtype=np.float64)
+        # the DataFrame the reference builds from its per-measure lists (:466-479): column order and values
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            engine.save_time_series()
+        frame = engine.df
+        df_values = np.array([np.asarray(frame[col].to_numpy(), dtype=np.complex128) for col in frame.columns]).T
     out = {k: np.array(v) for k, v in rec.items()}
+    out.update(df_columns=np.array([str(c) for c in frame.columns]), df_values=df_values)
     out.update(normals=normals, uniforms=uniforms, constants=consts,
                term_names=np.array(term_names), stream_seed=np.array(stream_seed))
     path = os.path.join(GOLDEN_DIR, "traj_%s.npz" % name)
