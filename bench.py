@@ -1,6 +1,6 @@
 """Headline benchmark: MC steps/sec (chains x sweeps), BASELINE.json config 2.
 
-    python bench.py --gpus 1 --steps 1000 --warmup 1000
+    python bench.py --gpus 1 --steps 4000 --warmup 1000
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -63,7 +63,7 @@ def cpu_baseline(seconds):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--chains-log2", type=int, default=20, help="chains per GPU = 2**this")
     ap.add_argument("--sweeps", type=int, default=1, help="sweeps fused per launch in the headline run")
@@ -90,7 +90,8 @@ def main():
     from metropolisengine_amd.distributed import pooled_statistics
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    distributed = "RANK" in os.environ           # launched by torch.distributed.run (also at --gpus 1)
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -100,7 +101,7 @@ def main():
                                  device=local_rank, chain_offset=rank * n_local)
 
     def fence():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -111,7 +112,7 @@ def main():
         dev_ms = engine.time_steps(n_launches, sweeps)     # enqueues, records events, waits for the stop event
         fence()
         wall = time.perf_counter() - t0
-        if world > 1:
+        if distributed:
             t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall, dev_ms = float(t[0]), float(t[1])
@@ -162,7 +163,7 @@ def main():
             "pooled_variance_mean": float(sum(stats["covariance"][i][i] for i in range(N_REAL)) / N_REAL),
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -150,7 +150,10 @@ def build_examples(force=False):
     """The shipped plugins: the cylinder-style user energy for BASELINE config 5 (2 real + 7 complex) and one
     kernel set outside KERNEL_DIMS, (3, 2), which exercises the compile-on-demand path of build_dims."""
     src = os.path.join(os.path.dirname(PKG_DIR), "examples", "user_energy_cylinder.h")
-    return [build_user_energy(src, "cylinder", 2, 7, force=force), build_dims(3, 2, force=force)]
+    build(verbose=False)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=2) as pool:
+        jobs = [pool.submit(build_user_energy, src, "cylinder", 2, 7, force), pool.submit(build_dims, 3, 2, force)]
+        return [job.result() for job in jobs]
 
 
 if __name__ == "__main__":

@@ -6,7 +6,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
-#include <mutex>
 #include <string>
 #include <vector>
 

@@ -23,7 +23,6 @@ enum StatusBits : uint32_t {
 };
 
 constexpr int kBlockThreads = 256;  // 4 wavefronts; one lane owns one chain
-constexpr int kMaxCoeffs = 8;       // small by-value coefficient sets (dense matrices travel by pointer)
 
 // Type-erased launch descriptors; scalars are doubles and are narrowed by the typed launcher.
 struct StepLaunch {

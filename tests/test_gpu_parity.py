@@ -45,11 +45,6 @@ CASES = {
 }
 
 
-def _engine_state(eng):
-    x = eng._get(0)
-    return x
-
-
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_f64_trajectories_follow_the_oracle(name):
     nr, nc, spec, oracle_energy, temp, real0, cplx0, spm, nm, rej, oracle_rej = CASES[name]
