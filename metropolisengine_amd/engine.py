@@ -86,7 +86,10 @@ class MetropolisEngine:
             # the reference accepts [real, complex] but then breaks in mixed engines (quirk Q7)
             if initial_real_params is not None and initial_complex_params is not None:
                 raise ValueError("a [real, complex] sampling_width list is not usable with mixed parameter spaces")
+            initial_widths = (float(sampling_width[0]), float(sampling_width[1]))               # :94-95
             sampling_width = sampling_width[0] if initial_real_params is not None else sampling_width[1]
+        else:
+            initial_widths = (float(sampling_width), float(sampling_width))                     # :97-99
 
         real0 = np.zeros(0) if initial_real_params is None else np.asarray(initial_real_params, dtype=np.float64).ravel()
         cplx0 = (np.zeros(0, dtype=np.complex128) if initial_complex_params is None
@@ -101,7 +104,7 @@ class MetropolisEngine:
         self.chain_offset = int(chain_offset)
         self.temp = temp
         self.target_acceptance = target_acceptance
-        self._initial_width = float(sampling_width)
+        self._initial_widths = initial_widths     # what the width of an absent group stays at
         # "magnitude-phase" swaps step_complex_group only; step_all keeps the Gaussian sampler (:129-130, quirk Q9)
         self.complex_sample_method = ("magnitude-phase" if complex_sample_method == "magnitude-phase"
                                       else "multivariate-gaussian")
@@ -334,11 +337,11 @@ class MetropolisEngine:
     @property
     def real_group_sampling_width(self):
         # pure-complex engines never touch the real width (:449-456)
-        return self._width(1) if self.num_real_params else self._initial_width
+        return self._width(1) if self.num_real_params else self._initial_widths[0]
 
     @property
     def complex_group_sampling_width(self):
-        return self._width(2) if self.num_complex_params else self._initial_width
+        return self._width(2) if self.num_complex_params else self._initial_widths[1]
 
     @property
     def energy_total(self):
