@@ -60,6 +60,54 @@ def cpu_baseline(seconds):
                       "on %d cores for %.0f s each; steps/s summed" % (cores, seconds)}
 
 
+def other_configs(me, device, chains_log2):
+    """Informational side measurements (not the headline): the float64 build of the same kernel and the protocols of
+    BASELINE.json configs 3-5, each through the public API incl. measure() launches."""
+    import numpy as np
+    out = {}
+    n = 1 << chains_log2
+    f64 = me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * N_REAL, None, temp=1.0, n_chains=n, seed=2026,
+                              dtype="f64", device=device)
+    f64.time_steps(50, 1)
+    ms = f64.time_steps(200, 1) / 200
+    out["config2_f64"] = {"chain_steps_per_s": n / (ms * 1e-3), "ms_per_launch": ms,
+                          "state_GBps": 2 * BYTES_PER_CHAIN_STEP * n / (ms * 1e-3) / 1e9}
+    del f64
+
+    def protocol(engine, n_chains, steps_per_measure, cycles, warm_cycles):
+        for _ in range(warm_cycles):
+            engine.step_all(steps_per_measure)
+            engine.measure()
+        engine.sync()
+        t0 = time.perf_counter()
+        for _ in range(cycles):
+            for _ in range(steps_per_measure):
+                engine.step_all()
+            engine.measure()
+        engine.sync()
+        dt = time.perf_counter() - t0
+        return {"chain_steps_per_s": n_chains * steps_per_measure * cycles / dt,
+                "acceptance_rate": engine.acceptance_rate(), "chains": n_chains,
+                "protocol": "(%d x step_all + measure) x %d" % (steps_per_measure, cycles)}
+
+    a = b = (1.0, 2.0, 4.0, 8.0)
+    out["config3"] = protocol(me.MetropolisEngine(me.DiagQuadratic(a, b), None, [0.0] * 4, [0j] * 4, temp=1.0, n_chains=n,
+                                                  seed=2026, device=device), n, 10, 100, 60)
+    m = np.random.default_rng(5).standard_normal((64, 64))
+    e4 = me.MetropolisEngine(me.DenseQuadratic(m @ m.T / 64 + np.identity(64)), None, [0.0] * 64, None, temp=1.0,
+                             n_chains=n // 2, seed=2026, cov_mode="fixed", device=device)
+    e4.time_steps(50, 1)
+    ms = e4.time_steps(100, 1) / 100
+    out["config4"] = {"chain_steps_per_s": (n // 2) / (ms * 1e-3), "ms_per_launch": ms, "chains": n // 2,
+                      "state_GBps": (8 * 64 + 16) * (n // 2) / (ms * 1e-3) / 1e9, "kernel": "k_step_dense64_mfma"}
+    del e4
+    src = os.path.join(ROOT, "examples", "user_energy_cylinder.h")
+    out["config5"] = protocol(me.MetropolisEngine(me.UserEnergy("cylinder", src, (1.0, 0.5, 1.0)),
+                                                  me.AbsReal0AtLeast(1.0), [0.1, 0.0], [0.05] * 7, temp=0.1,
+                                                  n_chains=n // 4, seed=2026, device=device), n // 4, 10, 100, 60)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +117,8 @@ def main():
     ap.add_argument("--sweeps", type=int, default=1, help="sweeps fused per launch in the headline run")
     ap.add_argument("--fused-sweeps", type=int, default=32, help="extra fused-sweep measurement (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length (0 = skip)")
+    ap.add_argument("--extras", type=int, default=1, help="1: also time the float64 build of the headline kernel and "
+                    "BASELINE configs 3-5 (single GPU only; informational, a few seconds)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -139,6 +189,10 @@ def main():
     stats = pooled_statistics(engine)                      # the one collective: RCCL all-reduce of pooled moments
     engine.sync()
 
+    extras = None
+    if world == 1 and args.extras:
+        extras = other_configs(me, local_rank, args.chains_log2)
+
     if rank == 0:
         line = {
             "metric": "MC steps/sec (chains x sweeps) at 2^20 chains, 16 params",
@@ -159,6 +213,7 @@ def main():
                                  % args.chains_log2},
             "cpu_baseline": cpu,
             "fused": fused,
+            "other_configs": extras,
             "acceptance_rate": stats["acceptance_rate"],
             "pooled_variance_mean": float(sum(stats["covariance"][i][i] for i in range(N_REAL)) / N_REAL),
         }
