@@ -371,7 +371,7 @@ int me_create(const me_config *c, me_engine **out) {
   ME_CREATE_HIP(hipMalloc(&e->shared_factor, (size_t)e->p * es));
   if (e->nc == 0) ME_CREATE_HIP(hipMalloc(&e->shared_full, (size_t)e->nr * e->nr * es));
   ME_CREATE_HIP(hipMalloc(&e->row_dev, (size_t)std::max(std::max(e->d, e->p), e->nobs) * es));
-  e->n_slots = (long long)grid_for(e->n, e->grid_blocks) * (kBlockThreads / 64);
+  e->n_slots = (e->n + 63) / 64 + 8;   // one slot per wavefront of the largest grid any step kernel uses
   ME_CREATE_HIP(hipMalloc((void **)&e->accept_slots, (size_t)e->n_slots * sizeof(unsigned long long)));
   ME_CREATE_HIP(hipMalloc((void **)&e->accept_total, sizeof(unsigned long long)));
   ME_CREATE_HIP(hipMalloc((void **)&e->status, sizeof(unsigned int)));

@@ -241,9 +241,9 @@ __host__ __device__ constexpr int cdiag(int pr, int i) { return pr + i * i + 2 *
 #define ME_STEP_WAVES_PER_EU 0
 #endif
 #if ME_STEP_WAVES_PER_EU > 0
-#define ME_STEP_BOUNDS __launch_bounds__(kBlockThreads, ME_STEP_WAVES_PER_EU)
+#define ME_STEP_BOUNDS __launch_bounds__(kFusedStepThreads, ME_STEP_WAVES_PER_EU)
 #else
-#define ME_STEP_BOUNDS __launch_bounds__(kBlockThreads)
+#define ME_STEP_BOUNDS __launch_bounds__(kFusedStepThreads)
 #endif
 // GROUP selects which coordinates move: GROUP_ALL = step_all (:241-259); GROUP_REAL / GROUP_COMPLEX = a mixed
 // engine's step_real_group / step_complex_group called directly (:209-239).  The word layout of a step is the same
@@ -265,10 +265,10 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
 
   unsigned int wave_accepted = 0;
   bool bad_energy = false, bad_width = false;
-  const long long stride = (long long)gridDim.x * kBlockThreads;
+  const long long stride = (long long)gridDim.x * blockDim.x;   // 64 threads per block, or 256 for fused sweeps
   const Field<R> fx(a.x, a.n, D), fe(a.energy, a.n, 1), fw(a.width, a.n, MIXED ? 3 : 1);
   const Field<R> ffac(a.factor, a.n, CK == CK_PER_CHAIN ? NR * (NR + 1) / 2 + NC * NC : 0);
-  for (long long c = (long long)blockIdx.x * kBlockThreads + threadIdx.x; c < a.n; c += stride) {
+  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
     R x[D];
 #pragma unroll
@@ -394,7 +394,7 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   // slot per launch.  (Same-address atomics serialise at ~12 ns each at the memory side: 2^14 wavefronts adding
   // to one counter cost 0.4 ms per launch, 15x the whole state sweep.)  Slots are summed on demand by k_sum_slots.
   if ((threadIdx.x & 63) == 0 && wave_accepted) {
-    unsigned long long *slot = a.accept_slots + (size_t)blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
+    unsigned long long *slot = a.accept_slots + (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     *slot += (unsigned long long)wave_accepted;
   }
   const unsigned int bits = (bad_energy ? ST_NONFINITE_ENERGY : 0u) | (bad_width ? ST_BAD_WIDTH : 0u);
@@ -402,11 +402,11 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
 }
 
 template <typename R, int NR, int NC, class Energy>
-__global__ void __launch_bounds__(kBlockThreads) k_init_energy(const R *xs, R *energy, long long n, unsigned int *status,
+__global__ void __launch_bounds__(kStepThreads) k_init_energy(const R *xs, R *energy, long long n, unsigned int *status,
                                                                 Energy en) {
   constexpr int D = NR + 2 * NC;
-  const long long stride = (long long)gridDim.x * kBlockThreads;
-  for (long long c = (long long)blockIdx.x * kBlockThreads + threadIdx.x; c < n; c += stride) {
+  const long long stride = (long long)gridDim.x * kStepThreads;
+  for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < n; c += stride) {
     R x[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) x[d] = xs[(long long)d * n + c];
@@ -436,17 +436,17 @@ struct MeasureArgs {
 // of metropolis_engine.py:416-427 (mu_old mu_old^H - i/(i-1) mu mu^H + x x^H/(i-1) == delta delta^H / i),
 // which has no cancellation when |mean| >> std and is therefore safe in fp32.
 template <typename R, int NR, int NC, bool PER_CHAIN_COV>
-__global__ void __launch_bounds__(kBlockThreads) k_measure(MeasureArgs<R> a) {
+__global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
   constexpr int D = NR + 2 * NC;
   constexpr int PR = NR * (NR + 1) / 2;
   constexpr int P = PR + NC * NC;
   constexpr int NOBS = 2 * NR + NC;
   using N_ = Num<R>;
   bool bad_pivot = false;
-  const long long stride = (long long)gridDim.x * kBlockThreads;
+  const long long stride = (long long)gridDim.x * kStepThreads;
   const Field<R> fx(a.x, a.n, D), fw(a.width, a.n, (NR > 0 && NC > 0) ? 3 : 1), fmean(a.mean, a.n, D), fobs(a.obs_mean, a.n, NOBS);
   const Field<R> fcov(a.cov, a.n, PER_CHAIN_COV ? P : 0), ffac(a.factor, a.n, PER_CHAIN_COV ? P : 0);
-  for (long long c = (long long)blockIdx.x * kBlockThreads + threadIdx.x; c < a.n; c += stride) {
+  for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
     R x[D], delta[D];
 #pragma unroll

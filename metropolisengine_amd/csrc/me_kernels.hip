@@ -137,7 +137,8 @@ hipError_t launch_step_group(const StepLaunch &l, const StepArgs<R> &a, const En
 template <typename R, class Energy>
 hipError_t step_with(const StepLaunch &l, const Energy &en, hipStream_t stream) {
   const StepArgs<R> a = typed<R>(l);
-  const dim3 grid(grid_for(l.n, l.grid_blocks)), block(kBlockThreads);
+  const int threads = l.n_sweeps >= kFusedSweepsThreshold ? kFusedStepThreads : kStepThreads;
+  const dim3 grid(grid_for(l.n, l.grid_blocks, threads)), block(threads);
   if (l.inj_normals) {
     // injected-stream replay: float64 only (it exists to check trajectories against the float64 reference)
     if constexpr (std::is_same<R, double>::value) return launch_step_group<R, Energy, true>(l, a, en, grid, block, stream);
@@ -166,7 +167,7 @@ hipError_t magphase_with(const StepLaunch &l, const Energy &en, hipStream_t stre
   if constexpr (NC > 0) {
     StepArgs<R> a = typed<R>(l);
     a.factor = (const R *)l.cov;
-    const dim3 grid(grid_for(l.n, l.grid_blocks)), block(kBlockThreads);
+    const dim3 grid(grid_for(l.n, l.grid_blocks)), block(kStepThreads);
     if (l.inj_normals) {
       if constexpr (std::is_same<R, double>::value)
         hipLaunchKernelGGL((k_step_magphase<R, NR, NC, Energy, true>), grid, block, 0, stream, a, en);
@@ -254,7 +255,7 @@ template <typename R>
 hipError_t init_energy(const EnergyLaunch &l, hipStream_t stream) {
   return with_energy<R>(l.energy_kind, l.coef_host, l.n_coef, l.coef_device, [&](const auto &en) {
     using Energy = std::decay_t<decltype(en)>;
-    hipLaunchKernelGGL((k_init_energy<R, NR, NC, Energy>), dim3(grid_for(l.n, l.grid_blocks)), dim3(kBlockThreads), 0,
+    hipLaunchKernelGGL((k_init_energy<R, NR, NC, Energy>), dim3(grid_for(l.n, l.grid_blocks)), dim3(kStepThreads), 0,
                        stream, (const R *)l.x, (R *)l.energy, l.n, l.status, en);
     return hipGetLastError();
   });
@@ -278,7 +279,7 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
   a.update_cov = l.update_cov;
   a.split_widths = l.split_widths;
   a.write_factor = l.write_factor;
-  hipLaunchKernelGGL((k_measure<R, NR, NC, ME_PER_CHAIN != 0>), dim3(grid_for(l.n, l.grid_blocks)), dim3(kBlockThreads), 0,
+  hipLaunchKernelGGL((k_measure<R, NR, NC, ME_PER_CHAIN != 0>), dim3(grid_for(l.n, l.grid_blocks)), dim3(kStepThreads), 0,
                      stream, a);
   return hipGetLastError();
 }

@@ -37,7 +37,7 @@ struct Trig<double> {
 
 // a.factor carries the per-chain covariance field (ME_FIELD_COV), not the proposal factors.
 template <typename R, int NR, int NC, class Energy, bool INJECT = false>
-__global__ void __launch_bounds__(kBlockThreads) k_step_magphase(StepArgs<R> a, Energy en) {
+__global__ void __launch_bounds__(kStepThreads) k_step_magphase(StepArgs<R> a, Energy en) {
   static_assert(NC > 0, "the magnitude-phase sampler acts on complex parameters");
   constexpr int D = NR + 2 * NC;
   constexpr int PR = NR * (NR + 1) / 2;
@@ -51,9 +51,9 @@ __global__ void __launch_bounds__(kBlockThreads) k_step_magphase(StepArgs<R> a, 
 
   unsigned int wave_accepted = 0;
   bool bad_energy = false, bad_width = false;
-  const long long stride = (long long)gridDim.x * kBlockThreads;
+  const long long stride = (long long)gridDim.x * kStepThreads;
   const Field<R> fx(a.x, a.n, D), fe(a.energy, a.n, 1), fw(a.width, a.n, MIXED ? 3 : 1), fcov(a.factor, a.n, P);
-  for (long long c = (long long)blockIdx.x * kBlockThreads + threadIdx.x; c < a.n; c += stride) {
+  for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
     R x[D], kdiag[NC];
 #pragma unroll
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(kBlockThreads) k_step_magphase(StepArgs<R> a, 
     fw.store(WROW, coff, w);
   }
   if ((threadIdx.x & 63) == 0 && wave_accepted) {
-    unsigned long long *slot = a.accept_slots + (size_t)blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
+    unsigned long long *slot = a.accept_slots + (size_t)blockIdx.x * (kStepThreads / 64) + (threadIdx.x >> 6);
     *slot += (unsigned long long)wave_accepted;
   }
   const unsigned int bits = (bad_energy ? ST_NONFINITE_ENERGY : 0u) | (bad_width ? ST_BAD_WIDTH : 0u);
