@@ -508,5 +508,26 @@ class MetropolisEngine:
         print(self.df)                                                                   # :479
 
     def save_equilibrium_stats(self, external_df=None):
-        raise NotImplementedError("equilibration statistics (metropolis_engine.py:481-504) depend on pymbar and are "
-                                  "outside the accelerated hot path; see DESIGN.md")
+        """metropolis_engine.py:481-504: equilibration point per recorded column, the global cut-off (largest ``t0``
+        over the columns that are not sampling widths) and the re-averaged means.  PARITY UNPINNED: the reference
+        delegates to pymbar, which is absent; see metropolisengine_amd/statistics.py."""
+        import pandas
+        from . import statistics
+        if self.df is None:
+            self.save_time_series()
+        if external_df is not None:
+            frames = [self.df] + [df for df in external_df if isinstance(df.iloc[0, 0], (float, int))]   # :486
+            all_df = pandas.concat(frames, axis=1)
+        else:
+            all_df = self.df
+        self.eq_points = statistics.get_equilibration_points(all_df)
+        self.global_eq_point = max(t for key, (t, _, _) in self.eq_points.items() if "sampling_width" not in key)
+        self.equilibrated_means, self.eq_means_error = statistics.get_equilibrated_means(self.df,
+                                                                                         cutoff=self.global_eq_point)
+        if external_df is not None:
+            profiles = [statistics.get_equilibrated_means(e_df, cutoff=self.global_eq_point)[0] for e_df in external_df]
+            self.field_profile = profiles[0]                                             # :501-502
+            if len(profiles) > 1:
+                self.field_abs_profile = profiles[1]
+        print("global t_0", self.global_eq_point)                                        # :503
+        self.equilibrated_means["global_cutoff"] = self.global_eq_point
