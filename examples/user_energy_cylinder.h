@@ -7,6 +7,13 @@
 //   coef            {kappa, gamma, wavenumber}
 #include "metropolis_user_energy.h"
 
+#define ME_USER_HAS_REJECT
+// the cylinder's hard wall: the surface amplitude must stay inside (-1, 1)   (/metropolis_engine.py:139-141)
+template <typename R>
+__device__ bool me_user_reject(const R *x, const R *coef) {
+  return !(x[0] > R(-1) && x[0] < R(1));
+}
+
 template <typename R>
 __device__ R me_user_energy(const R *x, const R *coef) {
   const R kappa = coef[0], gamma = coef[1], wavenumber = coef[2];

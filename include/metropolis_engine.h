@@ -67,7 +67,8 @@ typedef enum me_energy_kind {
 /* Hard-wall predicate evaluated before the energy (metropolis_engine.py:142-146, :247-249). */
 typedef enum me_reject_kind {
   ME_REJECT_NONE = 0,
-  ME_REJECT_ABS_REAL0_GE = 1 /* reject when |x_0| >= reject_bound  (legacy /metropolis_engine.py:139-141) */
+  ME_REJECT_ABS_REAL0_GE = 1, /* reject when |x_0| >= reject_bound  (legacy /metropolis_engine.py:139-141) */
+  ME_REJECT_USER = 2          /* the plugin's me_user_reject (include/metropolis_user_energy.h); user energies only */
 } me_reject_kind;
 
 /* Which matrix shapes the proposals. */

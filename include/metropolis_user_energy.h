@@ -20,7 +20,12 @@
  * which registers itself when loaded with me_load_plugin(path); engines select it with
  * me_config.energy_kind = ME_ENERGY_USER (inlined call) or ME_ENERGY_USER_INDIRECT (call through a __device__
  * function pointer held in the plugin's code object) and me_config.user_energy_name = "mine".
- * A hard-wall predicate stays in me_config.reject_kind (evaluated before the energy, metropolis_engine.py:247).
+ * The hard-wall predicate (reject_condition, metropolis_engine.py:142-146, evaluated before the energy, :247) is either
+ * the built-in me_config.reject_kind = ME_REJECT_ABS_REAL0_GE or, with ME_REJECT_USER, a second device function the same
+ * source file defines after  #define ME_USER_HAS_REJECT :
+ *
+ *     template <typename R>
+ *     __device__ bool me_user_reject(const R *x, const R *coef);      // true = reject the proposal
  */
 #ifndef METROPOLIS_USER_ENERGY_H
 #define METROPOLIS_USER_ENERGY_H

@@ -5,9 +5,9 @@ mirrors ``import metropolisengine as me`` of the reference (README.md:13-17, met
 The HIP library is loaded on first use of an engine; there is no CPU fallback.
 """
 from .energy import (AbsReal0AtLeast, CylinderSurrogate, DenseQuadratic, DiagQuadratic, EnergySpec, IsoQuadratic,
-                     LandauToy, RejectSpec, UserEnergy)
+                     LandauToy, RejectSpec, UserEnergy, UserReject)
 from .engine import MetropolisEngine
 
 __all__ = ["MetropolisEngine", "EnergySpec", "IsoQuadratic", "DiagQuadratic", "DenseQuadratic", "LandauToy",
-           "CylinderSurrogate", "UserEnergy", "RejectSpec", "AbsReal0AtLeast"]
+           "CylinderSurrogate", "UserEnergy", "RejectSpec", "AbsReal0AtLeast", "UserReject"]
 __version__ = "0.1.0"

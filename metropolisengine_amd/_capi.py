@@ -13,7 +13,7 @@ ME_OK, ME_ERR_INVALID, ME_ERR_UNSUPPORTED, ME_ERR_HIP, ME_ERR_NUMERIC, ME_ERR_ST
 ME_F32, ME_F64 = 0, 1
 (ENERGY_ISO_QUAD, ENERGY_DIAG_QUAD, ENERGY_DENSE_QUAD, ENERGY_LANDAU_TOY, ENERGY_CYLINDER, ENERGY_USER,
  ENERGY_USER_INDIRECT) = range(7)
-REJECT_NONE, REJECT_ABS_REAL0_GE = 0, 1
+REJECT_NONE, REJECT_ABS_REAL0_GE, REJECT_USER = 0, 1, 2
 STEP_ALL, STEP_REAL_GROUP, STEP_COMPLEX_GROUP, STEP_COMPLEX_MAGNITUDE_PHASE = range(4)
 COV_REFERENCE, COV_FIXED, COV_POOLED = 0, 1, 2
 (FIELD_PARAMS, FIELD_ENERGY, FIELD_WIDTH, FIELD_MEAN, FIELD_COV, FIELD_OBS_MEAN, FIELD_FACTOR) = range(7)

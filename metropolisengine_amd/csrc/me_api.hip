@@ -283,6 +283,10 @@ int me_create(const me_config *c, me_engine **out) {
   if (!c->initial_params) return fail(nullptr, ME_ERR_INVALID, "initial_params is required");
   if (c->n_energy_coeffs < 0 || (c->n_energy_coeffs > 0 && !c->energy_coeffs))
     return fail(nullptr, ME_ERR_INVALID, "energy coefficients missing");
+  if (c->reject_kind < ME_REJECT_NONE || c->reject_kind > ME_REJECT_USER)
+    return fail(nullptr, ME_ERR_INVALID, "unknown reject_kind");
+  if (c->reject_kind == ME_REJECT_USER && c->energy_kind != ME_ENERGY_USER && c->energy_kind != ME_ENERGY_USER_INDIRECT)
+    return fail(nullptr, ME_ERR_INVALID, "ME_REJECT_USER needs a user-energy plugin (it supplies me_user_reject)");
   if (c->cov_mode < ME_COV_REFERENCE || c->cov_mode > ME_COV_POOLED)
     return fail(nullptr, ME_ERR_INVALID, "unknown cov_mode");
   const KernelSet *ks = find_kernel_set(c->dtype, c->n_real, c->n_complex, c->energy_kind, c->user_energy_name);

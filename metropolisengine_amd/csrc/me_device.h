@@ -209,6 +209,17 @@ struct EnergyCylinder {  // cylinder-style surrogate, see oracle/energies.py:cyl
   }
 };
 
+// A user-energy plugin may also supply the hard-wall predicate (ME_REJECT_USER): Energy::reject(x).  Built-in
+// energies have none; the second overload answers "never reject" for them.
+template <class E, typename R, int D>
+__device__ __forceinline__ auto energy_reject(const E &en, const R (&x)[D], int) -> decltype(en.reject(x)) {
+  return en.reject(x);
+}
+template <class E, typename R, int D>
+__device__ __forceinline__ bool energy_reject(const E &, const R (&)[D], long) {
+  return false;
+}
+
 // ------------------------------------------------------------------------------------------------ k_step
 template <typename R>
 struct StepArgs {
@@ -368,6 +379,7 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
       // ---- hard wall before the energy (:247-249), energy, accept rule (:319-338)
       bool rejected = false;
       if (a.reject_kind == ME_REJECT_ABS_REAL0_GE) rejected = !(N_::abs_(xp[0]) < a.reject_bound);
+      else if (a.reject_kind == ME_REJECT_USER) rejected = energy_reject(en, xp, 0);
       const R e_new = en(xp);
       const R diff = e_new - e;
       bool accept = diff <= R(0);

@@ -40,6 +40,9 @@ struct EnergyUser {
   static constexpr int D = NR_ + 2 * NC_;
   const R *coef;
   __device__ __forceinline__ R operator()(const R (&x)[D]) const { return me_user_energy<R>(x, coef); }
+#ifdef ME_USER_HAS_REJECT
+  __device__ __forceinline__ bool reject(const R (&x)[D]) const { return me_user_reject<R>(x, coef); }
+#endif
 };
 // Indirect form: the call goes through a __device__ function pointer read from the plugin's code object
 // (BASELINE config 5: "user-callback energy via device fn pointer"); costs a real call and a private-memory x.
@@ -55,6 +58,9 @@ struct EnergyUserIndirect {
   user_fn_t<R> fn;
   const R *coef;
   __device__ __forceinline__ R operator()(const R (&x)[D]) const { return fn(x, coef); }
+#ifdef ME_USER_HAS_REJECT
+  __device__ __forceinline__ bool reject(const R (&x)[D]) const { return me_user_reject<R>(x, coef); }
+#endif
 };
 template <typename R>
 user_fn_t<R> load_user_fn() {

@@ -68,6 +68,7 @@ __global__ void __launch_bounds__(kStepThreads) k_step_magphase(StepArgs<R> a, E
     auto decide = [&](const R (&xp)[D], R u) -> bool {
       bool rejected = false;
       if (a.reject_kind == ME_REJECT_ABS_REAL0_GE) rejected = !(N_::abs_(xp[0]) < a.reject_bound);
+      else if (a.reject_kind == ME_REJECT_USER) rejected = energy_reject(en, xp, 0);
       const R e_new = en(xp);
       const R diff = e_new - e;
       bool accept = diff <= R(0);

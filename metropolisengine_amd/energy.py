@@ -125,6 +125,11 @@ class RejectSpec:
     bound = 0.0
 
 
+class UserReject(RejectSpec):
+    """The ``me_user_reject`` device function of the engine's :class:`UserEnergy` plugin (ME_REJECT_USER)."""
+    kind = _capi.REJECT_USER
+
+
 class AbsReal0AtLeast(RejectSpec):
     """Hard wall ``|x_0| >= bound`` (the legacy engine's ``abs(amplitude) >= 1``, /metropolis_engine.py:139-141)."""
     kind = _capi.REJECT_ABS_REAL0_GE
