@@ -60,6 +60,26 @@ def cpu_baseline(seconds):
                       "on %d cores for %.0f s each; steps/s summed" % (cores, seconds)}
 
 
+def cpu_baseline_c(seconds):
+    """The plain-C restatement (oracle/c/me_oracle.c, float64, OpenMP over chains) on config 2: the strong CPU
+    baseline next to the Python port.  Same Philox streams and arithmetic as the float64 GPU kernels."""
+    from oracle.c_oracle import COracle
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    n = 1 << 16
+    chains = COracle(N_REAL, 0, a=[1.0] * N_REAL, n_chains=n, seed=2026, temp=1.0, initial_real_params=[0.0] * N_REAL)
+    chains.step(20)
+    done = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        chains.step(50)
+        done += 50
+    dt = time.perf_counter() - t0
+    return {"value": n * done / dt, "unit": "chain-steps/s", "cores": cores, "kind": "port",
+            "sample": "oracle/c/me_oracle.c (float64, OpenMP), config 2 with 2^16 chains x %d sweeps in %.1f s, "
+                      "acceptance %.3f" % (done, dt, chains.accepted / chains.proposed)}
+
+
 def other_configs(me, device, chains_log2):
     """Informational side measurements (not the headline): the float64 build of the same kernel and the protocols of
     BASELINE.json configs 3-5, each through the public API incl. measure() launches."""
@@ -130,9 +150,10 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
     # CPU baseline first: child processes are started before this process touches the GPU
-    cpu = None
+    cpu = cpu_c = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         cpu = cpu_baseline(args.cpu_seconds)
+        cpu_c = cpu_baseline_c(min(args.cpu_seconds, 6.0))
 
     import torch
     import torch.distributed as dist
@@ -212,6 +233,7 @@ def main():
                                  "launch duration from HIP events on the engine's stream over the timed region"
                                  % args.chains_log2},
             "cpu_baseline": cpu,
+            "cpu_baseline_c": cpu_c,
             "fused": fused,
             "other_configs": extras,
             "acceptance_rate": stats["acceptance_rate"],
