@@ -447,7 +447,61 @@ struct MeasureArgs {
 //     C <- C (i-2)/(i-1) + (x - mu_old)(x - mu_old)^H / i + (sigma^2 / i) I
 // of metropolis_engine.py:416-427 (mu_old mu_old^H - i/(i-1) mu mu^H + x x^H/(i-1) == delta delta^H / i),
 // which has no cancellation when |mean| >> std and is therefore safe in fp32.
-template <typename R, int NR, int NC, bool PER_CHAIN_COV>
+// In-register Cholesky of the packed proposal matrix (real block, then the Hermitian block which must already hold
+// conj(K), quirk Q3): m is overwritten by the factor.  A non-positive pivot is flagged and clamped.
+template <typename R, int NR, int NC>
+__device__ __forceinline__ void cholesky_packed(R (&m)[NR * (NR + 1) / 2 + NC * NC], bool &bad_pivot) {
+  constexpr int PR = NR * (NR + 1) / 2;
+  using N_ = Num<R>;
+    // in-register Cholesky, real block
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      R s = m[tri(j, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= m[tri(j, k)] * m[tri(j, k)];
+      if (!(s > R(0))) { bad_pivot = true; s = R(1e-30); }
+      const R dg = N_::sqrt_(s);
+      const R inv = R(1) / dg;
+      m[tri(j, j)] = dg;
+#pragma unroll
+      for (int i = j + 1; i < NR; ++i) {
+        R t = m[tri(i, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) t -= m[tri(i, k)] * m[tri(j, k)];
+        m[tri(i, j)] = t * inv;
+      }
+    }
+    // complex Hermitian block: L L^H = conj(K)
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      R s = m[cdiag(PR, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= m[cre(PR, j, k)] * m[cre(PR, j, k)] + m[cim(PR, j, k)] * m[cim(PR, j, k)];
+      if (!(s > R(0))) { bad_pivot = true; s = R(1e-30); }
+      const R dg = N_::sqrt_(s);
+      const R inv = R(1) / dg;
+      m[cdiag(PR, j)] = dg;
+#pragma unroll
+      for (int i = j + 1; i < NC; ++i) {
+        R tr = m[cre(PR, i, j)], ti = m[cim(PR, i, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) {
+          // t -= L_ik conj(L_jk)
+          const R ar = m[cre(PR, i, k)], ai2 = m[cim(PR, i, k)];
+          const R br = m[cre(PR, j, k)], bi2 = m[cim(PR, j, k)];
+          tr -= ar * br + ai2 * bi2;
+          ti -= ai2 * br - ar * bi2;
+        }
+        m[cre(PR, i, j)] = tr * inv;
+        m[cim(PR, i, j)] = ti * inv;
+      }
+    }
+}
+
+// FUSED = true refreshes the proposal factors in the same kernel (the updated covariance stays in registers); for
+// large packed sizes that costs occupancy on the streaming part (16 real parameters: 236 VGPRs, 2 wavefronts per
+// SIMD, 2.2 TB/s), so there the factors are refreshed by k_factor in a second launch (FUSED = false).
+template <typename R, int NR, int NC, bool PER_CHAIN_COV, bool FUSED>
 __global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
   constexpr int D = NR + 2 * NC;
   constexpr int PR = NR * (NR + 1) / 2;
@@ -516,57 +570,41 @@ __global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
           fcov.store(kd, coff, vd);
           m[kd] = vd;
         }
-        if (a.write_factor) {
-          // in-register Cholesky, real block
+        if constexpr (FUSED) {
+          if (a.write_factor) {
+            cholesky_packed<R, NR, NC>(m, bad_pivot);
 #pragma unroll
-          for (int j = 0; j < NR; ++j) {
-            R s = m[tri(j, j)];
-#pragma unroll
-            for (int k = 0; k < j; ++k) s -= m[tri(j, k)] * m[tri(j, k)];
-            if (!(s > R(0))) { bad_pivot = true; s = R(1e-30); }
-            const R dg = N_::sqrt_(s);
-            const R inv = R(1) / dg;
-            m[tri(j, j)] = dg;
-#pragma unroll
-            for (int i = j + 1; i < NR; ++i) {
-              R t = m[tri(i, j)];
-#pragma unroll
-              for (int k = 0; k < j; ++k) t -= m[tri(i, k)] * m[tri(j, k)];
-              m[tri(i, j)] = t * inv;
-            }
+            for (int k = 0; k < P; ++k) ffac.store(k, coff, m[k]);
           }
-          // complex Hermitian block: L L^H = conj(K)
-#pragma unroll
-          for (int j = 0; j < NC; ++j) {
-            R s = m[cdiag(PR, j)];
-#pragma unroll
-            for (int k = 0; k < j; ++k) s -= m[cre(PR, j, k)] * m[cre(PR, j, k)] + m[cim(PR, j, k)] * m[cim(PR, j, k)];
-            if (!(s > R(0))) { bad_pivot = true; s = R(1e-30); }
-            const R dg = N_::sqrt_(s);
-            const R inv = R(1) / dg;
-            m[cdiag(PR, j)] = dg;
-#pragma unroll
-            for (int i = j + 1; i < NC; ++i) {
-              R tr = m[cre(PR, i, j)], ti = m[cim(PR, i, j)];
-#pragma unroll
-              for (int k = 0; k < j; ++k) {
-                // t -= L_ik conj(L_jk)
-                const R ar = m[cre(PR, i, k)], ai2 = m[cim(PR, i, k)];
-                const R br = m[cre(PR, j, k)], bi2 = m[cim(PR, j, k)];
-                tr -= ar * br + ai2 * bi2;
-                ti -= ai2 * br - ar * bi2;
-              }
-              m[cre(PR, i, j)] = tr * inv;
-              m[cim(PR, i, j)] = ti * inv;
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < P; ++k) ffac.store(k, coff, m[k]);
         }
       }
     }
   }
   if (bad_pivot) atomicOr(a.status, (unsigned int)ST_BAD_PIVOT);
+}
+
+// Refresh the per-chain proposal factors from the per-chain covariance: factor = chol(C_r), chol(conj(K)).
+template <typename R, int NR, int NC>
+__global__ void __launch_bounds__(kStepThreads) k_factor(const R *cov, R *factor, unsigned int *status, long long n) {
+  constexpr int PR = NR * (NR + 1) / 2;
+  constexpr int P = PR + NC * NC;
+  bool bad_pivot = false;
+  const long long stride = (long long)gridDim.x * kStepThreads;
+  const Field<R> fcov(cov, n, P), ffac(factor, n, P);
+  for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < n; c += stride) {
+    const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
+    R m[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) m[k] = fcov.load(k, coff);
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int j = 0; j < i; ++j) m[cim(PR, i, j)] = -m[cim(PR, i, j)];   // conj(K) (quirk Q3, :292-298)
+    cholesky_packed<R, NR, NC>(m, bad_pivot);
+#pragma unroll
+    for (int k = 0; k < P; ++k) ffac.store(k, coff, m[k]);
+  }
+  if (bad_pivot) atomicOr(status, (unsigned int)ST_BAD_PIVOT);
 }
 
 }  // namespace me

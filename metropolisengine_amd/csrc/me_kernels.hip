@@ -23,6 +23,9 @@
 #ifndef ME_PER_CHAIN
 #define ME_PER_CHAIN 1
 #endif
+#ifndef ME_MEASURE_FUSED_MAX_P
+#define ME_MEASURE_FUSED_MAX_P 56   // largest packed size whose Cholesky is fused into k_measure ((2,7): 52 fused; (16,0): 136 split)
+#endif
 
 namespace me {
 namespace {
@@ -285,8 +288,17 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
   a.update_cov = l.update_cov;
   a.split_widths = l.split_widths;
   a.write_factor = l.write_factor;
-  hipLaunchKernelGGL((k_measure<R, NR, NC, ME_PER_CHAIN != 0>), dim3(grid_for(l.n, l.grid_blocks)), dim3(kStepThreads), 0,
-                     stream, a);
+  // small packed matrices: one fused launch; large ones: streaming update, then the factor kernel (see k_measure)
+  constexpr int P = NR * (NR + 1) / 2 + NC * NC;
+  constexpr bool kFused = P <= ME_MEASURE_FUSED_MAX_P;
+  const dim3 grid(grid_for(l.n, l.grid_blocks)), block(kStepThreads);
+  hipLaunchKernelGGL((k_measure<R, NR, NC, ME_PER_CHAIN != 0, kFused>), grid, block, 0, stream, a);
+#if ME_PER_CHAIN
+  if constexpr (!kFused) {
+    if (l.update_cov && l.write_factor)
+      hipLaunchKernelGGL((k_factor<R, NR, NC>), grid, block, 0, stream, (const R *)l.cov, (R *)l.factor, l.status, l.n);
+  }
+#endif
   return hipGetLastError();
 }
 
