@@ -141,6 +141,9 @@ typedef enum me_step_kind_t {
 } me_step_kind_t;
 int me_step_kind(me_engine *engine, int32_t kind, int32_t n_sweeps);
 int me_measure(me_engine *engine);
+/* set_reject_condition (metropolis_engine.py:142-146): the wall predicate is a launch parameter and may be changed
+ * between steps (in the reference this setter is the only working way to install one, quirk Q6). */
+int me_set_reject_condition(me_engine *engine, int32_t reject_kind, double reject_bound);
 /* Test hook (float64 engines): the same step with the random draws supplied by the caller instead of Philox --
  * for the Gaussian kinds normals [n_sweeps][n_chains][D] standard normals and uniforms [n_sweeps][n_chains][1] accept
  * draws; for ME_STEP_COMPLEX_MAGNITUDE_PHASE normals [n_sweeps][n_chains][nc] and uniforms [n_sweeps][n_chains][nc+2]

@@ -46,6 +46,7 @@ SYMBOLS = {
     "me_step": (ctypes.c_int, [_H, ctypes.c_int32]),
     "me_measure": (ctypes.c_int, [_H]),
     "me_step_kind": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32]),
+    "me_set_reject_condition": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_double]),
     "me_step_injected": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32, _dp, _dp]),
     "me_field_components": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
     "me_get": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, _dp]),

@@ -287,6 +287,8 @@ int me_create(const me_config *c, me_engine **out) {
     return fail(nullptr, ME_ERR_INVALID, "unknown reject_kind");
   if (c->reject_kind == ME_REJECT_USER && c->energy_kind != ME_ENERGY_USER && c->energy_kind != ME_ENERGY_USER_INDIRECT)
     return fail(nullptr, ME_ERR_INVALID, "ME_REJECT_USER needs a user-energy plugin (it supplies me_user_reject)");
+  if (c->reject_kind == ME_REJECT_ABS_REAL0_GE && c->n_real == 0)
+    return fail(nullptr, ME_ERR_INVALID, "ME_REJECT_ABS_REAL0_GE needs a real parameter");
   if (c->cov_mode < ME_COV_REFERENCE || c->cov_mode > ME_COV_POOLED)
     return fail(nullptr, ME_ERR_INVALID, "unknown cov_mode");
   const KernelSet *ks = find_kernel_set(c->dtype, c->n_real, c->n_complex, c->energy_kind, c->user_energy_name);
@@ -454,6 +456,18 @@ int me_create(const me_config *c, me_engine **out) {
     return rc;
   }
   *out = e;
+  return ME_OK;
+}
+
+int me_set_reject_condition(me_engine *e, int32_t reject_kind, double reject_bound) {
+  if (!e) return ME_ERR_INVALID;
+  if (reject_kind < ME_REJECT_NONE || reject_kind > ME_REJECT_USER) return fail(e, ME_ERR_INVALID, "unknown reject_kind");
+  if (reject_kind == ME_REJECT_USER && e->energy_kind != ME_ENERGY_USER && e->energy_kind != ME_ENERGY_USER_INDIRECT)
+    return fail(e, ME_ERR_INVALID, "ME_REJECT_USER needs a user-energy plugin (it supplies me_user_reject)");
+  if (reject_kind == ME_REJECT_ABS_REAL0_GE && e->nr == 0)
+    return fail(e, ME_ERR_INVALID, "ME_REJECT_ABS_REAL0_GE needs a real parameter");
+  e->reject_kind = reject_kind;     // a launch parameter: takes effect from the next step
+  e->reject_bound = reject_bound;
   return ME_OK;
 }
 

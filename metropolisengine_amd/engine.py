@@ -254,8 +254,14 @@ class MetropolisEngine:
 
     # ------------------------------------------------------------------ setters (:136-149)
     def set_reject_condition(self, reject_fct):
-        raise NotImplementedError("the wall predicate is compiled into the launch configuration: pass "
-                                  "reject_condition=AbsReal0AtLeast(bound) to the constructor")
+        """metropolis_engine.py:142-146 (in the reference the only working way to install a constraint, quirk Q6).
+        ``reject_fct`` is a :class:`~metropolisengine_amd.energy.RejectSpec` or ``None`` (no constraint)."""
+        if reject_fct is not None and not isinstance(reject_fct, RejectSpec):
+            raise TypeError("reject_condition must be a metropolisengine_amd.energy.RejectSpec or None")
+        kind = reject_fct.kind if reject_fct is not None else _capi.REJECT_NONE
+        bound = reject_fct.bound if reject_fct is not None else 0.0
+        self._check(self._lib.me_set_reject_condition(self._handle, int(kind), float(bound)))
+        self._reject_spec = reject_fct
 
     def set_energy_function(self, energy_function):
         raise NotImplementedError("pass the EnergySpec to the constructor; term dictionaries "

@@ -106,3 +106,25 @@ def test_numeric_failures_surface_as_exceptions():
         eng._check(eng._lib.me_recompute_energy(eng._handle))
         eng.sync()
     eng.sync()                                 # the flags are cleared once reported
+
+
+def test_set_reject_condition_after_construction():
+    """The reference's constructor drops ``reject_condition`` (quirk Q6); its users install the wall with
+    ``set_reject_condition`` (metropolis_engine.py:142-146).  Both routes must give the same chain."""
+    args = (me.DiagQuadratic((0.5,), (1.0,)), )
+    kw = dict(initial_real_params=[0.0], initial_complex_params=[0.1j], temp=1.0, n_chains=512, seed=4)
+    ctor = me.MetropolisEngine(*args, reject_condition=me.AbsReal0AtLeast(0.25), **kw)
+    setter = me.MetropolisEngine(*args, **kw)
+    setter.set_reject_condition(me.AbsReal0AtLeast(0.25))
+    free = me.MetropolisEngine(*args, **kw)
+    for eng in (ctor, setter, free):
+        eng.step_all(200)
+    assert np.array_equal(ctor._get(0), setter._get(0)) and ctor.accept_stats() == setter.accept_stats()
+    assert np.all(np.abs(setter._get(0)[:, 0]) < 0.25) and np.any(np.abs(free._get(0)[:, 0]) >= 0.25)
+    setter.set_reject_condition(None)                 # lifting the wall
+    setter.step_all(400)
+    assert np.any(np.abs(setter._get(0)[:, 0]) >= 0.25)
+    with pytest.raises(TypeError):
+        setter.set_reject_condition(lambda r, c: False)
+    with pytest.raises(ValueError):
+        me.MetropolisEngine(me.IsoQuadratic(1.0), me.AbsReal0AtLeast(1.0), None, [0j], temp=1.0, n_chains=8)
