@@ -124,7 +124,7 @@ struct me_engine {
   int width_rows = 1;           // 3 for mixed engines: [sampling_width, real group, complex group]
   bool widths_synced = true;    // mixed engines: rows 1, 2 are implied equal to row 0 (state after a step_all)
   unsigned int *status = nullptr;
-  double *pool_dev = nullptr;
+  double *pool_dev = nullptr, *pool_partials = nullptr;
   // time-series trace of a few chains (the reference's per-measure appends, :350-356)
   double *trace_dev = nullptr;
   long long trace_chains = 0, trace_stride = 1, trace_rows = 0, trace_capacity = 0;
@@ -250,7 +250,7 @@ void release(me_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   void *bufs[] = {e->x, e->energy, e->width, e->mean, e->cov, e->obs_mean, e->factor, e->shared_factor, e->shared_full,
-                  e->coef_dev, e->row_dev, e->accept_slots, e->accept_total, e->status, e->pool_dev, e->trace_dev};
+                  e->coef_dev, e->row_dev, e->accept_slots, e->accept_total, e->status, e->pool_dev, e->pool_partials, e->trace_dev};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -382,6 +382,9 @@ int me_create(const me_config *c, me_engine **out) {
   ME_CREATE_HIP(hipMalloc((void **)&e->accept_total, sizeof(unsigned long long)));
   ME_CREATE_HIP(hipMalloc((void **)&e->status, sizeof(unsigned int)));
   ME_CREATE_HIP(hipMalloc((void **)&e->pool_dev, sizeof(double) * (size_t)moments_size(e->nr, e->nc)));
+  ME_CREATE_HIP(hipMalloc((void **)&e->pool_partials,
+                          sizeof(double) * (size_t)pool_reduce_blocks(e->n, e->nr, e->nc) *
+                              (size_t)(1 + e->d + e->nr + e->nc + e->d * (e->d + 1) / 2)));
   ME_CREATE_HIP(hipMemsetAsync(e->accept_slots, 0, (size_t)e->n_slots * sizeof(unsigned long long), e->stream));
   ME_CREATE_HIP(hipMemsetAsync(e->status, 0, sizeof(unsigned int), e->stream));
   if (e->energy_kind == ME_ENERGY_DENSE_QUAD || (is_user_kind(e->energy_kind) && !e->coef.empty())) {
@@ -807,7 +810,7 @@ int me_pooled_moments_device(me_engine *e, void *device_out, int64_t n_doubles) 
   ME_HIP(e, hipSetDevice(e->device));
   ME_HIP(e, launch_sum_slots(e->accept_slots, e->n_slots, e->accept_total, e->stream));
   hipError_t err = launch_pool_reduce(e->x, e->n, e->nr, e->nc, e->dtype, e->accept_total, (double)e->proposed,
-                                      (double *)device_out, e->stream);
+                                      e->pool_partials, (double *)device_out, e->stream);
   if (err == hipErrorInvalidValue) return fail(e, ME_ERR_UNSUPPORTED, "pooled moments: dimension too large for the reduction kernel");
   ME_HIP(e, err);
   ME_HIP(e, hipStreamSynchronize(e->stream));

@@ -11,18 +11,26 @@ __global__ void __launch_bounds__(kBlockThreads) k_broadcast_rows(R *dst, const 
     for (int r = 0; r < rows; ++r) dst[(long long)r * n + c] = row_values[r];
 }
 
+// (i, j), i >= j, of packed lower-triangle index p
+__device__ __forceinline__ void pair_of(int p, int &i, int &j) {
+  i = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+  while (i * (i + 1) / 2 > p) --i;
+  while ((i + 1) * (i + 2) / 2 <= p) ++i;
+  j = p - i * (i + 1) / 2;
+}
+
 constexpr int kTileChains = 64;   // chains staged per LDS tile
 constexpr int kTilePitch = 65;    // +1 pad: threads walk different rows at the same column
 constexpr int kMaxEntries = 12;   // moment entries per thread -> up to 3072 entries per engine
 
-// k_pool_reduce: S = sum over chains of [1, x, x x^T (lower), |x_r|, |z_c|, x_r^2] in fp64.
-// A block stages a tile of 64 chains x (D + nr + nc) augmented rows in LDS; every thread owns a fixed set of
-// output entries and walks the tile's 64 columns for each; per-block partial sums go out as fp64 atomics
-// (global_atomic_add_f64), one per entry per block.  Output order: me_pooled_moments in the public header.
+// k_pool_reduce: S = sum over chains of [1, x, x x^T (lower), |x_r|, |z_c|] in fp64, in two launches.
+// Stage 1: a block stages a tile of 64 chains x (D + nr + nc) augmented rows in LDS; every thread owns a fixed set of
+// entries and walks the tile's 64 columns for each (in the device dtype within a tile, fp64 across tiles); per-block
+// partial sums are written to partials[block][entry].  Stage 2 (k_pool_finish) sums the partials per entry and writes
+// the result in the public order (me_pooled_moments).  No atomics: a thousand blocks adding to the same ~200 words
+// with fp64 atomics serialise at the memory side (measured: the one-launch atomic version was 2x slower).
 template <typename R>
-__global__ void __launch_bounds__(kBlockThreads) k_pool_reduce(const R *x, long long n, int nr, int nc,
-                                                               const unsigned long long *accepted_total, double proposed,
-                                                               double *out) {
+__global__ void __launch_bounds__(kBlockThreads) k_pool_reduce(const R *x, long long n, int nr, int nc, double *partials) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R *tile = reinterpret_cast<R *>(smem_raw);
   const int d = nr + 2 * nc;
@@ -31,33 +39,21 @@ __global__ void __launch_bounds__(kBlockThreads) k_pool_reduce(const R *x, long 
   const int n_entries = 1 + n_aug + n_pair;
   const int tid = threadIdx.x;
 
-  // decode this thread's entries once: kind 0 = count, 1 = row sum, 2 = pair product
-  int row_i[kMaxEntries], row_j[kMaxEntries], out_idx[kMaxEntries], out_idx2[kMaxEntries];
+  // decode this thread's entries once: entry 0 = count, 1..n_aug = row sums, then the pair products (i >= j)
+  int row_i[kMaxEntries], row_j[kMaxEntries];
+  bool active[kMaxEntries];
   double acc[kMaxEntries];
 #pragma unroll
   for (int k = 0; k < kMaxEntries; ++k) {
     const int e = tid + k * kBlockThreads;
     acc[k] = 0.0;
     row_i[k] = row_j[k] = -1;
-    out_idx[k] = out_idx2[k] = -1;
-    if (e >= n_entries) continue;
-    if (e == 0) {
-      out_idx[k] = 0;
-    } else if (e <= n_aug) {
-      const int r = e - 1;
-      row_i[k] = r;
-      if (r < d) out_idx[k] = 1 + r;                                  // sum x
-      else out_idx[k] = 1 + d + n_pair + (r - d);                     // sum |x_r|, sum |z_c|
+    active[k] = e < n_entries;
+    if (!active[k] || e == 0) continue;
+    if (e <= n_aug) {
+      row_i[k] = e - 1;
     } else {
-      const int p = e - 1 - n_aug;
-      int i = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
-      while (i * (i + 1) / 2 > p) --i;
-      while ((i + 1) * (i + 2) / 2 <= p) ++i;
-      const int j = p - i * (i + 1) / 2;
-      row_i[k] = i;
-      row_j[k] = j;
-      out_idx[k] = 1 + d + p;
-      if (i == j && i < nr) out_idx2[k] = 1 + d + n_pair + nr + nc + i;  // sum x_r^2 (observable)
+      pair_of(e - 1 - n_aug, row_i[k], row_j[k]);
     }
   }
 
@@ -86,34 +82,65 @@ __global__ void __launch_bounds__(kBlockThreads) k_pool_reduce(const R *x, long 
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kMaxEntries; ++k) {
-      if (out_idx[k] < 0) continue;
+      if (!active[k]) continue;
       if (row_i[k] < 0) {
         acc[k] += (double)valid;
       } else if (row_j[k] < 0) {
         const R *ri = tile + row_i[k] * kTilePitch;
-        double s = 0.0;
-        for (int col = 0; col < kTileChains; ++col) s += (double)ri[col];
-        acc[k] += s;
+        R s = 0;
+        for (int col = 0; col < kTileChains; ++col) s += ri[col];
+        acc[k] += (double)s;
       } else {
         const R *ri = tile + row_i[k] * kTilePitch;
         const R *rj = tile + row_j[k] * kTilePitch;
-        double s = 0.0;
-        for (int col = 0; col < kTileChains; ++col) s += (double)ri[col] * (double)rj[col];
-        acc[k] += s;
+        R s = 0;
+        for (int col = 0; col < kTileChains; ++col) s += ri[col] * rj[col];
+        acc[k] += (double)s;
       }
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int k = 0; k < kMaxEntries; ++k) {
-    if (out_idx[k] < 0) continue;
-    atomicAdd(&out[out_idx[k]], acc[k]);
-    if (out_idx2[k] >= 0) atomicAdd(&out[out_idx2[k]], acc[k]);
+  for (int k = 0; k < kMaxEntries; ++k)
+    if (active[k]) partials[(long long)blockIdx.x * n_entries + tid + k * kBlockThreads] = acc[k];
+}
+
+// Stage 2: 64 entries x 4 block-slices per workgroup; a thread sums every 4th block's partial of its entry (consecutive
+// lanes read consecutive entries: coalesced; 8 independent loads in flight), the slices meet in LDS, and the total
+// goes where the public layout wants it.
+__global__ void __launch_bounds__(kBlockThreads) k_pool_finish(const double *partials, int n_blocks, int nr, int nc,
+                                                               const unsigned long long *accepted_total, double proposed,
+                                                               double *out) {
+  __shared__ double part[4][64];
+  const int d = nr + 2 * nc;
+  const int n_aug = d + nr + nc;
+  const int n_pair = d * (d + 1) / 2;
+  const int n_entries = 1 + n_aug + n_pair;
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  double s = 0.0;
+  if (e < n_entries) {
+#pragma unroll 8
+    for (int b = slice; b < n_blocks; b += 4) s += partials[(long long)b * n_entries + e];
   }
-  if (blockIdx.x == 0 && tid == 0) {
+  part[slice][lane] = s;
+  __syncthreads();
+  if (slice != 0) return;
+  s = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+  if (e == 0) {
     const long long size = moments_size(nr, nc);
     out[size - 2] = (double)accepted_total[0];
     out[size - 1] = proposed;
+    out[0] = s;                                            // n
+  } else if (e <= n_aug) {
+    const int r = e - 1;
+    out[r < d ? 1 + r : 1 + d + n_pair + (r - d)] = s;     // sum x | sum |x_r|, sum |z_c|
+  } else if (e < n_entries) {
+    const int p = e - 1 - n_aug;
+    int i, j;
+    pair_of(p, i, j);
+    out[1 + d + p] = s;                                    // sum x_i x_j
+    if (i == j && i < nr) out[1 + d + n_pair + nr + nc + i] = s;   // sum x_r^2 (observable)
   }
 }
 
@@ -177,9 +204,19 @@ hipError_t launch_sum_slots(const unsigned long long *slots, long long n_slots, 
   return hipGetLastError();
 }
 
+int pool_reduce_blocks(long long n, int nr, int nc) {
+  const int d = nr + 2 * nc;
+  const long long n_entries = 1 + d + nr + nc + (long long)d * (d + 1) / 2;
+  long long cap = (8ll << 20) / (8 * n_entries);   // at most 8 MiB of partials
+  if (cap > 1024) cap = 1024;
+  if (cap < 64) cap = 64;
+  const long long tiles = (n + kTileChains - 1) / kTileChains;
+  return (int)(tiles < cap ? (tiles < 1 ? 1 : tiles) : cap);
+}
+
 hipError_t launch_pool_reduce(const void *x, long long n, int nr, int nc, int dtype,
-                              const unsigned long long *accepted_total, double proposed, double *out_device,
-                              hipStream_t stream) {
+                              const unsigned long long *accepted_total, double proposed, double *partials,
+                              double *out_device, hipStream_t stream) {
   const int d = nr + 2 * nc;
   const int n_aug = d + nr + nc;
   const int n_entries = 1 + n_aug + d * (d + 1) / 2;
@@ -187,26 +224,27 @@ hipError_t launch_pool_reduce(const void *x, long long n, int nr, int nc, int dt
   const size_t elem = dtype == ME_F32 ? sizeof(float) : sizeof(double);
   const size_t lds = (size_t)n_aug * kTilePitch * elem;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  hipError_t err = hipMemsetAsync(out_device, 0, sizeof(double) * (size_t)moments_size(nr, nc), stream);
-  if (err != hipSuccess) return err;
-  long long tiles = (n + kTileChains - 1) / kTileChains;
-  long long blocks = tiles < 1024 ? tiles : 1024;
-  if (blocks < 1) blocks = 1;
+  const int blocks = pool_reduce_blocks(n, nr, nc);
+  hipError_t err;
   if (dtype == ME_F32) {
     if (lds > 64 * 1024) {
       err = hipFuncSetAttribute((const void *)k_pool_reduce<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (err != hipSuccess) return err;
     }
     hipLaunchKernelGGL(k_pool_reduce<float>, dim3((unsigned)blocks), dim3(kBlockThreads), lds, stream, (const float *)x, n,
-                       nr, nc, accepted_total, proposed, out_device);
+                       nr, nc, partials);
   } else {
     if (lds > 64 * 1024) {
       err = hipFuncSetAttribute((const void *)k_pool_reduce<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (err != hipSuccess) return err;
     }
     hipLaunchKernelGGL(k_pool_reduce<double>, dim3((unsigned)blocks), dim3(kBlockThreads), lds, stream, (const double *)x,
-                       n, nr, nc, accepted_total, proposed, out_device);
+                       n, nr, nc, partials);
   }
+  err = hipGetLastError();
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(k_pool_finish, dim3((unsigned)((n_entries + 63) / 64)), dim3(kBlockThreads),
+                     0, stream, (const double *)partials, blocks, nr, nc, accepted_total, proposed, out_device);
   return hipGetLastError();
 }
 

@@ -99,8 +99,10 @@ hipError_t launch_broadcast_rows(void *dst, const void *row_values, int rows, lo
 // Ensemble sums (see me_pooled_moments in the public header).  out must hold moments_size doubles and is
 // zeroed by the launcher; accepted_total is a device scalar (from launch_sum_slots), proposed is host-known.
 hipError_t launch_pool_reduce(const void *x, long long n, int n_real, int n_complex, int dtype,
-                              const unsigned long long *accepted_total, double proposed, double *out_device,
-                              hipStream_t stream);
+                              const unsigned long long *accepted_total, double proposed, double *partials,
+                              double *out_device, hipStream_t stream);
+// blocks of the first reduction stage; partials must hold pool_reduce_blocks(...) * (1 + D + nr + nc + D(D+1)/2) doubles
+int pool_reduce_blocks(long long n, int n_real, int n_complex);
 // Time-series row of the traced chains (chain t*stride, t < n_traced): out[col][t] as doubles with columns
 // [params (d) | energy | widths (width_rows)]  -- what measure() appends in the reference (:350-356).
 hipError_t launch_trace(const void *x, const void *energy, const void *width, long long n, int d, int width_rows,

@@ -224,7 +224,8 @@ def test_sharding_invariance_bitwise():
             e.measure()
     for field in range(7):
         assert np.array_equal(full._get(field), np.concatenate((lo._get(field), hi._get(field)))), field
-    assert np.allclose(full.pooled_moments(), lo.pooled_moments() + hi.pooled_moments(), rtol=1e-12)
+    # float32 engines sum each 64-chain tile in float32 (fp64 across tiles): shards tile differently -> ~1e-7 relative
+    assert np.allclose(full.pooled_moments(), lo.pooled_moments() + hi.pooled_moments(), rtol=5e-6, atol=1e-4)
 
 
 def test_checkpoint_round_trip():
@@ -312,7 +313,7 @@ def test_full_size_properties_config2():
     b.step_all(200)
     b.step_all(200)
     ma, mb = a.pooled_moments(), b.pooled_moments()
-    assert np.array_equal(ma, mb) or np.allclose(ma, mb, rtol=1e-12)   # fp64 atomics: order may differ in the last bit
+    assert np.array_equal(ma, mb)   # the two-stage reduction has a fixed summation order: bitwise reproducible
     assert np.array_equal(a._get(0, 12345, 4096), b._get(0, 12345, 4096))
     from metropolisengine_amd.distributed import moments_to_statistics
     st = moments_to_statistics(ma, 16, 0)
