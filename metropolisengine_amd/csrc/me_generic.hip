@@ -207,7 +207,7 @@ hipError_t launch_sum_slots(const unsigned long long *slots, long long n_slots, 
 int pool_reduce_blocks(long long n, int nr, int nc) {
   const int d = nr + 2 * nc;
   const long long n_entries = 1 + d + nr + nc + (long long)d * (d + 1) / 2;
-  long long cap = (8ll << 20) / (8 * n_entries);   // at most 8 MiB of partials
+  long long cap = (32ll << 20) / (8 * n_entries);   // at most 32 MiB of partials
   if (cap > 1024) cap = 1024;
   if (cap < 64) cap = 64;
   const long long tiles = (n + kTileChains - 1) / kTileChains;
