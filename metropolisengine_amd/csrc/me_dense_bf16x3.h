@@ -1,0 +1,275 @@
+// Y = M X on the bf16 matrix cores with fp32-level accuracy: both operands are split into three bf16 pieces
+// (truncation splits: v = v1 + v2 + v3 exactly captures >= 22 mantissa bits) and the six products whose piece
+// indices sum to <= 4 are accumulated in fp32:
+//     M X ~ M1 X1 + (M1 X2 + M2 X1) + (M1 X3 + M3 X1 + M2 X2),   neglected terms <= 2^-24 |M| |X|.
+// bf16 x bf16 products are exact in fp32, so the only rounding is the fp32 accumulation -- the same as any fp32
+// summation order.  Unlike v_mfma_f32_32x32x2_f32 (which occupies the fp32 VALU lanes, me_dense_mfma.h), the bf16
+// MFMAs run on the matrix pipe beside VALU work, and 96 v_mfma_f32_32x32x16_bf16 (32 cycles each) replace
+// 128 fp32 MFMAs of 64 cycles.
+//
+// One wavefront = 64 chains, one chain per lane.  Operand maps (guide section 3): lane l (r = l & 31, h = l >> 5) holds
+// A[row r][k = 8h + j] and B[k = 8h + j][col r], j = 0..7, of a 32x32x16 product; C/D as for every 32x32 shape.
+//   A fragments: prepared on the host in fragment order, [piece][row block][k step][lane][8 bf16], staged in LDS,
+//                read with ds_read_b128 (lane-linear, conflict-free).
+//   B fragments: a lane packs its own chain's pieces for k = 16s..16s+7 ("lo") and 16s+8..16s+15 ("hi");
+//                v_permlane32_swap(lo, hi) turns the pair into the operands of chain blocks 0 and 1.
+#pragma once
+
+#include <cstdlib>
+
+#include "me_dense_mfma.h"
+
+namespace me {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+
+constexpr int kBf16FragWords = 3 * 2 * 4 * 64 * 4;   // 32-bit words of the A fragments: 24 KiB
+
+// top 16 bits of a float (bf16 by truncation) and the exact remainder
+__device__ __forceinline__ float bf16_head(float v, float &rest) {
+  const float head = __uint_as_float(__float_as_uint(v) & 0xFFFF0000u);
+  rest = v - head;
+  return head;
+}
+// two bf16 heads -> one register {lo = a, hi = b}
+__device__ __forceinline__ unsigned int pack_bf16(float a, float b) {
+  return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xFFFF0000u);
+}
+
+struct Bf16Operands {   // this lane's chain, one piece, one k step: "lo" = params 16s..16s+7, "hi" = 16s+8..16s+15
+  unsigned int lo[4], hi[4];
+};
+
+__device__ __forceinline__ bf16x8 as_frag(const unsigned int (&w)[4]) {
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+  u32x4 v = {w[0], w[1], w[2], w[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// y = M x for the wave's 64 columns; x is read through `get(k)` (this lane's X[k]) and the result handed out row by
+// row through `emit(row, y[row])` (this lane's chain), so that no second 64-register array is live beside the
+// accumulators; frags = image of M's three bf16 pieces in fragment order (stage_bf16_fragments).
+template <class Get, class Emit>
+__device__ __forceinline__ void wave_matmul_64_bf16x3(const unsigned int *frags, Get &&get, Emit &&emit, int lane) {
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    // this lane's X[16s .. 16s+15] split once into its three pieces, packed two bf16 per register
+    Bf16Operands op[3];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      float piece[3][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float rest = get(16 * s + 2 * w + t);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) piece[q][t] = bf16_head(rest, rest);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const unsigned int packed = pack_bf16(piece[q][0], piece[q][1]);
+        if (w < 4) op[q].lo[w] = packed;
+        else op[q].hi[w - 4] = packed;
+      }
+    }
+    // chain block 0 <- [lo of lanes 0-31 | hi of lanes 0-31], chain block 1 <- [lo of lanes 32-63 | hi of lanes 32-63]
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        float a = __uint_as_float(op[q].lo[w]), b = __uint_as_float(op[q].hi[w]);
+        swap32(a, b);
+        op[q].lo[w] = __float_as_uint(a);
+        op[q].hi[w] = __float_as_uint(b);
+      }
+    // products with piece indices qa + qx <= 2 (0-based), small terms first within the k step
+#pragma unroll
+    for (int qa = 2; qa >= 0; --qa)
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const u32x4 raw = *reinterpret_cast<const u32x4 *>(frags + ((((qa * 2 + mb) * 4 + s) * 64 + lane) << 2));
+        const bf16x8 a = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+        for (int qx = 2 - qa; qx >= 0; --qx) {
+          acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, as_frag(op[qx].lo), acc[mb][0], 0, 0, 0);
+          acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, as_frag(op[qx].hi), acc[mb][1], 0, 0, 0);
+        }
+      }
+    __builtin_amdgcn_sched_barrier(0);   // keep the next k step's operand loads from piling up in registers
+  }
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float lo = acc[mb][0][r], hi = acc[mb][1][r];
+      swap32(lo, hi);                       // lo: own chain, row acc_row(r); hi: own chain, row acc_row(r) + 4
+      emit(32 * mb + acc_row(r), lo);
+      emit(32 * mb + acc_row(r) + 4, hi);
+    }
+}
+
+// Split the row-major fp32 matrix m[64][64] into its three bf16 pieces, in fragment order, into LDS.
+__device__ __forceinline__ void stage_bf16_fragments(unsigned int *lds_frag, const float *__restrict__ m) {
+  unsigned short *dst = reinterpret_cast<unsigned short *>(lds_frag);
+  for (int idx = threadIdx.x; idx < 4096; idx += blockDim.x) {
+    const int i = idx >> 6, k = idx & 63;
+    const int mb = i >> 5, s = k >> 4, lane = 32 * ((k >> 3) & 1) + (i & 31), j = k & 7;
+    float rest = m[idx];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float head = bf16_head(rest, rest);
+      dst[((((q * 2 + mb) * 4 + s) * 64 + lane) << 3) + j] = (unsigned short)(__float_as_uint(head) >> 16);
+    }
+  }
+}
+
+// The dense-64 sweep on the bf16 matrix pipe.  Same chain-per-lane geometry, stream contract and epilogue as
+// k_step_dense64_mfma; the proposals x' are parked in LDS between their production and the dot product / commit.
+// CK_IDENTITY keeps A's fragments in LDS (24 KiB + 128 KiB of proposals).  CK_SHARED has no room left for the factor's
+// fragments, so A's stay in LDS and L's are read from a global image the launcher prepares (24 KiB, L1/L2-resident).
+template <int CK>
+constexpr size_t dense64_bf16_lds_bytes() {
+  return sizeof(float) * (kBf16FragWords + 64 * kDenseBlockThreads);
+}
+
+template <int UNUSED = 0>
+__global__ void k_dense64_bf16_fragments(const float *__restrict__ m, unsigned int *__restrict__ out) {
+  __shared__ unsigned int frag[kBf16FragWords];
+  stage_bf16_fragments(frag, m);
+  __syncthreads();
+  for (int i = threadIdx.x; i < kBf16FragWords; i += blockDim.x) out[i] = frag[i];
+}
+
+template <int CK>
+__global__ void __launch_bounds__(kDenseBlockThreads, 2) k_step_dense64_bf16x3(StepArgs<float> a, const float *__restrict__ amat,
+                                                                             const unsigned int *lfrag) {
+  constexpr int D = 64;
+  using N_ = Num<float>;
+  extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
+  unsigned int *lds_a = smem_u;
+  float *lds_xp = reinterpret_cast<float *>(smem_u + kBf16FragWords) + threadIdx.x;   // this lane's column, stride 512
+  stage_bf16_fragments(lds_a, amat);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  unsigned int wave_accepted = 0;
+  bool bad_energy = false, bad_width = false;
+  const long long stride = (long long)gridDim.x * kDenseBlockThreads;
+  const Field<float> fx(a.x, a.n, D), fe(a.energy, a.n, 1), fw(a.width, a.n, 1);
+  // every lane stays active (MFMA and permlane need the whole wavefront): tail lanes shadow the last chain
+  for (long long base = (long long)blockIdx.x * kDenseBlockThreads + (threadIdx.x & ~63); base < a.n; base += stride) {
+    const long long c_raw = base + lane;
+    const bool live = c_raw < a.n;
+    const long long c = live ? c_raw : a.n - 1;
+    const unsigned int coff = (unsigned int)c * 4u;
+    float x[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = fx.load(d, coff);
+    float e = fe.load(0, coff);
+    float w = fw.load(0, coff);
+    const unsigned long long gid = a.chain_offset + (unsigned long long)c;
+
+    for (int s = 0; s < a.n_sweeps; ++s) {
+      const unsigned long long step = a.step_index + (unsigned long long)s;
+      U4 ctr;
+      ctr.x = (uint32_t)gid;
+      ctr.y = (uint32_t)(gid >> 32);
+      ctr.z = (uint32_t)step;
+      const uint32_t step_hi = (uint32_t)(step >> 32) << 16;
+      if constexpr (CK == CK_SHARED) {
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+          ctr.w = step_hi | (uint32_t)b;
+          const U4 r = philox4x32_10(ctr, a.seed_lo, a.seed_hi);
+          float g[4];
+          N_::normal_pair(r.x, r.y, g[0], g[1]);
+          N_::normal_pair(r.z, r.w, g[2], g[3]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) lds_xp[(4 * b + i) * kDenseBlockThreads] = g[i];
+        }
+        // x' = x + w L g; every lane has read all of g before the first row comes out.  The clobber keeps the
+        // (loop-invariant) fragment loads of L inside the sweep: hoisted, they would pin 96 registers.
+        asm volatile("" ::: "memory");
+        wave_matmul_64_bf16x3(lfrag, [&](int k) { return lds_xp[k * kDenseBlockThreads]; },
+                              [&](int row, float v) { lds_xp[row * kDenseBlockThreads] = x[row] + w * v; }, lane);
+      } else {
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+          ctr.w = step_hi | (uint32_t)b;
+          const U4 r = philox4x32_10(ctr, a.seed_lo, a.seed_hi);
+          float g[4];
+          N_::normal_pair(r.x, r.y, g[0], g[1]);
+          N_::normal_pair(r.z, r.w, g[2], g[3]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) lds_xp[(4 * b + i) * kDenseBlockThreads] = x[4 * b + i] + w * g[i];
+        }
+      }
+      float e_new = 0.0f;                                   // E = x'^T (A x')
+      wave_matmul_64_bf16x3(lds_a, [&](int k) { return lds_xp[k * kDenseBlockThreads]; },
+                            [&](int row, float v) { e_new += lds_xp[row * kDenseBlockThreads] * v; }, lane);
+      ctr.w = step_hi | 16u;                                // word 64 = block 16, output 0
+      const float u = N_::unit(philox4x32_10(ctr, a.seed_lo, a.seed_hi).x);
+      bool rejected = false;
+      if (a.reject_kind == ME_REJECT_ABS_REAL0_GE) rejected = !(N_::abs_(lds_xp[0]) < a.reject_bound);
+      const float diff = e_new - e;
+      bool accept = diff <= 0.0f;
+      if (a.temp > 0.0f) accept = accept || N_::uphill(u, diff, a.temp, a.inv_temp_log2e);
+      accept = accept && !rejected;
+      bad_energy |= (live && !rejected && !N_::finite(e_new));
+      if (accept) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) x[d] = lds_xp[d * kDenseBlockThreads];
+      }
+      e = accept ? e_new : e;
+      w = N_::adapt(w, accept, a.ratio, a.p, a.damping, a.up, a.down);
+      wave_accepted += (unsigned int)__popcll(__ballot(accept && live));
+    }
+    bad_width |= live && !(w > 0.0f);
+    if (live) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) fx.store(d, coff, x[d]);
+      fe.store(0, coff, e);
+      fw.store(0, coff, w);
+    }
+  }
+  if (lane == 0 && wave_accepted) {
+    unsigned long long *slot = a.accept_slots + (size_t)blockIdx.x * (kDenseBlockThreads / 64) + (threadIdx.x >> 6);
+    *slot += (unsigned long long)wave_accepted;
+  }
+  const unsigned int bits = (bad_energy ? ST_NONFINITE_ENERGY : 0u) | (bad_width ? ST_BAD_WIDTH : 0u);
+  if (bits) atomicOr(a.status, bits);
+}
+
+// METROPOLIS_DENSE64_FP32_MFMA=1 selects the fp32 MFMA kernel instead (read once per process).
+inline bool dense64_exact_fp32_mfma() {
+  static const bool on = [] {
+    const char *v = std::getenv("METROPOLIS_DENSE64_FP32_MFMA");
+    return v && v[0] == '1';
+  }();
+  return on;
+}
+
+// Host launcher.  lfrag (CK_SHARED): the factor's fragment image made by k_dense64_bf16_fragments.
+template <int CK>
+inline hipError_t launch_step_dense64_bf16x3(const StepArgs<float> &a, const float *amat, const unsigned int *lfrag,
+                                             int grid_blocks, hipStream_t stream) {
+  static const hipError_t attr = hipFuncSetAttribute((const void *)k_step_dense64_bf16x3<CK>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)dense64_bf16_lds_bytes<CK>());
+  if (attr != hipSuccess) return attr;
+  long long blocks = (a.n + kDenseBlockThreads - 1) / kDenseBlockThreads;
+  if (grid_blocks > 0 && blocks > grid_blocks) blocks = grid_blocks;
+  hipLaunchKernelGGL(k_step_dense64_bf16x3<CK>, dim3((unsigned)blocks), dim3(kDenseBlockThreads),
+                     dense64_bf16_lds_bytes<CK>(), stream, a, amat, lfrag);
+  return hipGetLastError();
+}
+
+}  // namespace me

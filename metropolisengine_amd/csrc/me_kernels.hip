@@ -6,6 +6,7 @@
 
 #include "me_device.h"
 #include "me_dense_mfma.h"
+#include "me_dense_bf16x3.h"
 #include "me_magphase.h"
 
 // User-energy plugin mode: -DME_USER_SOURCE='"file"' -DME_USER_NAME='"name"' compiles the SAME kernels around a
@@ -154,15 +155,21 @@ hipError_t step_with(const StepLaunch &l, const Energy &en, hipStream_t stream) 
     else return hipErrorNotSupported;
   }
 #if ME_DENSE && !defined(ME_USER_SOURCE)
-  // BASELINE config 4: 64 real parameters, dense quadratic form, fp32 -> matrix-core kernel (me_dense_mfma.h)
+  // BASELINE config 4: 64 real parameters, dense quadratic form, fp32 -> matrix-core kernels: split-bf16 on the matrix
+  // pipe (me_dense_bf16x3.h) or, with METROPOLIS_DENSE64_FP32_MFMA=1, the fp32 MFMA form (me_dense_mfma.h)
   if constexpr (std::is_same<R, float>::value && NR == 64 && NC == 0 &&
                 std::is_same<Energy, EnergyDense<float, 64, 0>>::value) {
-    if (l.cov_kind == CK_IDENTITY)
-      return launch_step_dense64_mfma<CK_IDENTITY>(a, en.a, nullptr, l.grid_blocks, stream);
-    if (l.cov_kind == CK_SHARED) {
-      if (!l.factor_full) return hipErrorInvalidValue;
-      return launch_step_dense64_mfma<CK_SHARED>(a, en.a, (const float *)l.factor_full, l.grid_blocks, stream);
+    if (dense64_exact_fp32_mfma()) {
+      if (l.cov_kind == CK_IDENTITY)
+        return launch_step_dense64_mfma<CK_IDENTITY>(a, en.a, nullptr, l.grid_blocks, stream);
+      if (l.cov_kind == CK_SHARED && l.factor_full)
+        return launch_step_dense64_mfma<CK_SHARED>(a, en.a, (const float *)l.factor_full, l.grid_blocks, stream);
+      return hipErrorInvalidValue;
     }
+    if (l.cov_kind == CK_IDENTITY)
+      return launch_step_dense64_bf16x3<CK_IDENTITY>(a, en.a, nullptr, l.grid_blocks, stream);
+    if (l.cov_kind == CK_SHARED && l.factor_image)
+      return launch_step_dense64_bf16x3<CK_SHARED>(a, en.a, (const unsigned int *)l.factor_image, l.grid_blocks, stream);
     return hipErrorInvalidValue;
   } else
 #endif
@@ -307,10 +314,26 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
 #else
 #define ME_SET_NAME nullptr
 #endif
+#if ME_DENSE && !defined(ME_USER_SOURCE)
+hipError_t prepare_factor_f32(const void *factor_full, void *image, hipStream_t stream) {
+  if constexpr (NR == 64 && NC == 0) {
+    hipLaunchKernelGGL(k_dense64_bf16_fragments<0>, dim3(1), dim3(256), 0, stream, (const float *)factor_full,
+                       (unsigned int *)image);
+    return hipGetLastError();
+  }
+  return hipSuccess;
+}
+constexpr size_t kFactorImageBytes = (NR == 64 && NC == 0) ? sizeof(unsigned int) * kBf16FragWords : 0;
+#define ME_PREPARE_FACTOR_F32 kFactorImageBytes, (kFactorImageBytes ? prepare_factor_f32 : nullptr)
+#else
+#define ME_PREPARE_FACTOR_F32 0, nullptr
+#endif
 const KernelSet kSetF32 = {ME_SET_NAME, ME_F32, NR, NC, ME_PER_CHAIN != 0, has_energy, step<float>,
-                           (NC > 0 && ME_PER_CHAIN) ? magphase<float> : nullptr, measure<float>, init_energy<float>};
+                           (NC > 0 && ME_PER_CHAIN) ? magphase<float> : nullptr, measure<float>, init_energy<float>,
+                           ME_PREPARE_FACTOR_F32};
 const KernelSet kSetF64 = {ME_SET_NAME, ME_F64, NR, NC, ME_PER_CHAIN != 0, has_energy, step<double>,
-                           (NC > 0 && ME_PER_CHAIN) ? magphase<double> : nullptr, measure<double>, init_energy<double>};
+                           (NC > 0 && ME_PER_CHAIN) ? magphase<double> : nullptr, measure<double>, init_energy<double>,
+                           0, nullptr};
 
 struct Registrar {
   Registrar() {

@@ -1,5 +1,10 @@
 """GPU tests of the matrix-core path for BASELINE config 4 (64 real parameters, E = x^T A x, float32):
-k_step_dense64_mfma against the float64 oracle (one step) and against the analytic stationary covariance T/2 A^-1."""
+k_step_dense64_bf16x3 (default; split-bf16 on the matrix pipe) and k_step_dense64_mfma (METROPOLIS_DENSE64_FP32_MFMA=1)
+against the float64 oracle (one step) and against the analytic stationary covariance T/2 A^-1."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -69,3 +74,16 @@ def test_mfma_matches_f64_kernel_statistics():
     b = moments_to_statistics(f64.pooled_moments(), 64, 0)
     assert abs(a["acceptance_rate"] - b["acceptance_rate"]) < 0.01
     assert np.all(np.abs(np.diag(a["covariance"]) - np.diag(b["covariance"])) < 8 * 0.5 * np.sqrt(2.0 / n))
+
+
+def test_fp32_mfma_variant_in_child_process():
+    """The kernel choice is read once per process: run the one-step and f64-statistics checks again under
+    METROPOLIS_DENSE64_FP32_MFMA=1 (one child test process)."""
+    if os.environ.get("METROPOLIS_DENSE64_FP32_MFMA") == "1":
+        pytest.skip("already the fp32 MFMA variant")
+    env = dict(os.environ, METROPOLIS_DENSE64_FP32_MFMA="1")
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                          "one_step or f64_kernel", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
+                         timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert "3 passed" in res.stdout
