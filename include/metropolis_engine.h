@@ -61,7 +61,9 @@ typedef enum me_energy_kind {
   ME_ENERGY_CYLINDER = 4,   /* coeffs {kappa, gamma, wavenumber}: cylinder-style surrogate */
   ME_ENERGY_USER = 5,       /* user-written device function from a plugin (include/metropolis_user_energy.h),
                                inlined into the kernels; coeffs are handed to it in device memory */
-  ME_ENERGY_USER_INDIRECT = 6 /* the same function called through a __device__ function pointer */
+  ME_ENERGY_USER_INDIRECT = 6, /* the same function called through a __device__ function pointer */
+  ME_ENERGY_LANDAU_TERMS = 7  /* the Landau toy as the reference demo passes it: a term dictionary {"field": both
+                                 groups, "area": real group} (demo/toymodel_complex_and_real.py:17-33); two ledger rows */
 } me_energy_kind;
 
 /* Hard-wall predicate evaluated before the energy (metropolis_engine.py:142-146, :247-249). */
@@ -82,7 +84,8 @@ typedef enum me_cov_mode {
 /* Per-chain fields for me_get / me_set; components per chain in brackets (P = nr(nr+1)/2 + nc^2). */
 typedef enum me_field {
   ME_FIELD_PARAMS = 0,   /* [D]  current state */
-  ME_FIELD_ENERGY = 1,   /* [1]  energy of the current state */
+  ME_FIELD_ENERGY = 1,   /* [T]  the energy ledger, one row per energy term (metropolis_engine.py:111-116, :152-155);
+                                 T = 1 ("total") unless the energy is a term dictionary (me_energy_terms) */
   ME_FIELD_WIDTH = 2,    /* [1] the group's sampling width; mixed engines [3]: sampling_width, real group, complex group */
   ME_FIELD_MEAN = 3,     /* [D]  running mean */
   ME_FIELD_COV = 4,      /* [P]  running covariance, packed: real block row-major lower triangle, then for
@@ -153,6 +156,9 @@ int me_set_reject_condition(me_engine *engine, int32_t reject_kind, double rejec
 int me_step_injected(me_engine *engine, int32_t kind, int32_t n_sweeps, const double *normals, const double *uniforms);
 
 int me_field_components(me_engine *engine, int32_t field, int32_t *n_components);
+/* Rows of the energy ledger = number of energy terms (self.energy_term_names, metropolis_engine.py:112-118).  Group
+ * steps re-evaluate and compare only the terms registered for their group (:214-221, :230-237). */
+int me_energy_terms(me_engine *engine, int32_t *n_terms);
 /* Copy chains [chain_begin, chain_begin + n_chains) of a field to/from host doubles [chain][component]. */
 int me_get(me_engine *engine, int32_t field, int64_t chain_begin, int64_t n_chains, double *dst);
 int me_set(me_engine *engine, int32_t field, int64_t chain_begin, int64_t n_chains, const double *src);

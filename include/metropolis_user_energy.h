@@ -26,6 +26,18 @@
  *
  *     template <typename R>
  *     __device__ bool me_user_reject(const R *x, const R *coef);      // true = reject the proposal
+ *
+ * Energy dictionaries (metropolis_engine.py:111-116: {"complex": {term: fn}, "real": {...}, "all": {...}}): instead
+ * of me_user_energy the source may define its energy term by term,
+ *
+ *     #define ME_USER_N_TERMS 2
+ *     constexpr unsigned me_user_term_groups(int term);   // bit 0: real-group moves change it, bit 1: complex-group
+ *     template <typename R>
+ *     __device__ R me_user_energy_term(int term, const R *x, const R *coef);
+ *
+ * The engine then keeps one energy row per term (ME_FIELD_ENERGY has ME_USER_N_TERMS components); step_real_group /
+ * step_complex_group re-evaluate and compare only their group's terms (:214-221, :230-237), step_all all of them;
+ * the total is the sum of the terms (:158-162).  Example: examples/user_energy_landau_terms.h.
  */
 #ifndef METROPOLIS_USER_ENERGY_H
 #define METROPOLIS_USER_ENERGY_H

@@ -12,7 +12,7 @@ ABI_VERSION = 1
 ME_OK, ME_ERR_INVALID, ME_ERR_UNSUPPORTED, ME_ERR_HIP, ME_ERR_NUMERIC, ME_ERR_STATE = range(6)
 ME_F32, ME_F64 = 0, 1
 (ENERGY_ISO_QUAD, ENERGY_DIAG_QUAD, ENERGY_DENSE_QUAD, ENERGY_LANDAU_TOY, ENERGY_CYLINDER, ENERGY_USER,
- ENERGY_USER_INDIRECT) = range(7)
+ ENERGY_USER_INDIRECT, ENERGY_LANDAU_TERMS) = range(8)
 REJECT_NONE, REJECT_ABS_REAL0_GE, REJECT_USER = 0, 1, 2
 STEP_ALL, STEP_REAL_GROUP, STEP_COMPLEX_GROUP, STEP_COMPLEX_MAGNITUDE_PHASE = range(4)
 COV_REFERENCE, COV_FIXED, COV_POOLED = 0, 1, 2
@@ -49,6 +49,7 @@ SYMBOLS = {
     "me_set_reject_condition": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_double]),
     "me_step_injected": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32, _dp, _dp]),
     "me_field_components": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
+    "me_energy_terms": (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
     "me_get": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, _dp]),
     "me_set": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, _dp]),
     "me_recompute_energy": (ctypes.c_int, [_H]),

@@ -185,12 +185,15 @@ def build_dims(n_real, n_complex, force=False):
 
 
 def build_examples(force=False):
-    """The shipped plugins: the cylinder-style user energy for BASELINE config 5 (2 real + 7 complex) and one
-    kernel set outside KERNEL_DIMS, (3, 2), which exercises the compile-on-demand path of build_dims."""
+    """The shipped plugins: the cylinder-style user energy for BASELINE config 5 (2 real + 7 complex), the term-wise
+    Landau plugin (energy dictionary, 2 real + 1 complex) and one kernel set outside KERNEL_DIMS, (3, 2), which
+    exercises the compile-on-demand path of build_dims."""
     src = os.path.join(REPO_DIR, "examples", "user_energy_cylinder.h")
+    terms = os.path.join(REPO_DIR, "examples", "user_energy_landau_terms.h")
     build(verbose=False)
-    with concurrent.futures.ThreadPoolExecutor(max_workers=2) as pool:
-        jobs = [pool.submit(build_user_energy, src, "cylinder", 2, 7, force), pool.submit(build_dims, 3, 2, force)]
+    with concurrent.futures.ThreadPoolExecutor(max_workers=3) as pool:
+        jobs = [pool.submit(build_user_energy, src, "cylinder", 2, 7, force), pool.submit(build_dims, 3, 2, force),
+                pool.submit(build_user_energy, terms, "landau_terms", 2, 1, force)]
         return [job.result() for job in jobs]
 
 

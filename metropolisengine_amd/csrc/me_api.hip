@@ -113,6 +113,7 @@ struct me_engine {
   int m = 0, energy_kind = 0, reject_kind = 0, cov_mode = 0;
   int cov_kind = CK_IDENTITY;
   int grid_blocks = 0;
+  int n_terms = 1;   // rows of the energy ledger (KernelSet::energy_terms)
   std::vector<double> coef;
   unsigned long long step_index = 0, measure_count = 1;   // counters start at 1 (metropolis_engine.py:72-75)
   // device buffers (SoA: component-major, chain-minor)
@@ -170,7 +171,7 @@ int broadcast(me_engine *e, void *dst, const std::vector<double> &row) {
 int field_info(me_engine *e, int field, void **ptr, int *comps) {
   switch (field) {
     case ME_FIELD_PARAMS: *ptr = e->x; *comps = e->d; return ME_OK;
-    case ME_FIELD_ENERGY: *ptr = e->energy; *comps = 1; return ME_OK;
+    case ME_FIELD_ENERGY: *ptr = e->energy; *comps = e->n_terms; return ME_OK;
     case ME_FIELD_WIDTH: *ptr = e->width; *comps = e->width_rows; return ME_OK;
     case ME_FIELD_MEAN: *ptr = e->mean; *comps = e->d; return ME_OK;
     case ME_FIELD_OBS_MEAN: *ptr = e->obs_mean; *comps = e->nobs; return ME_OK;
@@ -329,6 +330,7 @@ int me_create(const me_config *c, me_engine **out) {
   me_engine *e = new me_engine;
   e->device = c->device_id;
   e->ks = ks;
+  e->n_terms = ks->energy_terms(c->energy_kind);
   e->dtype = c->dtype;
   e->esize = c->dtype == ME_F32 ? 4 : 8;
   e->n = c->n_chains;
@@ -368,7 +370,7 @@ int me_create(const me_config *c, me_engine **out) {
   e->own_stream = true;
   const size_t n = (size_t)e->n, es = e->esize;
   ME_CREATE_HIP(hipMalloc(&e->x, n * e->d * es));
-  ME_CREATE_HIP(hipMalloc(&e->energy, n * es));
+  ME_CREATE_HIP(hipMalloc(&e->energy, n * e->n_terms * es));
   e->width_rows = (e->nr > 0 && e->nc > 0) ? 3 : 1;
   ME_CREATE_HIP(hipMalloc(&e->width, n * e->width_rows * es));
   ME_CREATE_HIP(hipMalloc(&e->mean, n * e->d * es));
@@ -635,7 +637,7 @@ int me_measure(me_engine *e) {
   ME_HIP(e, e->ks->measure(l, e->stream));
   if (l.write_factor) e->cov_kind = CK_PER_CHAIN;
   if (e->trace_chains > 0) {
-    const long long cols = e->d + 1 + e->width_rows;
+    const long long cols = e->d + e->n_terms + e->width_rows;
     if (e->trace_rows == e->trace_capacity) {   // grow the device-side series (doubling)
       const long long cap = e->trace_capacity ? 2 * e->trace_capacity : 1024;
       double *bigger = nullptr;
@@ -651,10 +653,10 @@ int me_measure(me_engine *e) {
     }
     // widths: a synced mixed engine keeps only row 0 current; mirror it so that the series reads like the reference's
     const int rows_valid = (e->width_rows == 3 && e->widths_synced) ? 1 : e->width_rows;
-    ME_HIP(e, launch_trace(e->x, e->energy, e->width, e->n, e->d, rows_valid, e->dtype, e->trace_chains, e->trace_stride,
+    ME_HIP(e, launch_trace(e->x, e->energy, e->width, e->n, e->d, e->n_terms, rows_valid, e->dtype, e->trace_chains, e->trace_stride,
                            e->trace_dev + e->trace_rows * cols * e->trace_chains, e->stream));
     if (rows_valid != e->width_rows) {
-      double *row = e->trace_dev + e->trace_rows * cols * e->trace_chains + (size_t)(e->d + 1) * e->trace_chains;
+      double *row = e->trace_dev + e->trace_rows * cols * e->trace_chains + (size_t)(e->d + e->n_terms) * e->trace_chains;
       for (int r = 1; r < 3; ++r)
         ME_HIP(e, hipMemcpyAsync(row + (size_t)r * e->trace_chains, row, sizeof(double) * (size_t)e->trace_chains,
                                  hipMemcpyDeviceToDevice, e->stream));
@@ -681,14 +683,14 @@ int me_trace_enable(me_engine *e, int64_t n_traced, int64_t stride) {
 int me_trace_shape(me_engine *e, int64_t *rows, int64_t *cols, int64_t *n_traced) {
   if (!e) return ME_ERR_INVALID;
   if (rows) *rows = e->trace_rows;
-  if (cols) *cols = e->d + 1 + e->width_rows;
+  if (cols) *cols = e->d + e->n_terms + e->width_rows;
   if (n_traced) *n_traced = e->trace_chains;
   return ME_OK;
 }
 
 int me_trace_get(me_engine *e, double *dst, int64_t n_doubles) {
   if (!e || !dst) return ME_ERR_INVALID;
-  const long long want = e->trace_rows * (e->d + 1 + e->width_rows) * e->trace_chains;
+  const long long want = e->trace_rows * (e->d + e->n_terms + e->width_rows) * e->trace_chains;
   if (n_doubles != want) return fail(e, ME_ERR_INVALID, "wrong trace buffer length");
   if (want == 0) return ME_OK;
   ME_HIP(e, hipSetDevice(e->device));
@@ -704,6 +706,12 @@ int me_field_components(me_engine *e, int32_t field, int32_t *n_components) {
   int rc = field_info(e, field, &ptr, &comps);
   if (rc == ME_OK) *n_components = comps;
   return rc;
+}
+
+int me_energy_terms(me_engine *e, int32_t *n_terms) {
+  if (!e || !n_terms) return ME_ERR_INVALID;
+  *n_terms = e->n_terms;
+  return ME_OK;
 }
 
 int me_get(me_engine *e, int32_t field, int64_t chain_begin, int64_t n_chains, double *dst) {

@@ -9,6 +9,8 @@
 // The random streams are the counter-based Philox4x32-10 streams specified in oracle/philox.py.
 #pragma once
 
+#include <type_traits>
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -209,6 +211,26 @@ struct EnergyCylinder {  // cylinder-style surrogate, see oracle/energies.py:cyl
   }
 };
 
+// The two-term dictionary form of the Landau toy (demo/toymodel_complex_and_real.py:17-33): "field" depends on both
+// groups, "area" on the real group only.  Term-wise energies expose kTerms, term_groups(t) (bit 0: the real group
+// moves it, bit 1: the complex group) and term(t, x); see EnergyLedger below.
+template <typename R, int NR, int NC>
+struct EnergyLandauTerms {
+  static constexpr int D = NR + 2 * NC;
+  static constexpr int kTerms = 2;
+  R k, alpha, beta;
+  static constexpr unsigned term_groups(int t) { return t == 0 ? 3u : 1u; }
+  __device__ __forceinline__ R term(int t, const R (&x)[D]) const {
+    static_assert(NR == 2 && NC == 1, "Landau toy is 2 real + 1 complex");
+    if (t == 0) {
+      const R a2 = x[2] * x[2] + x[3] * x[3];
+      return x[0] * x[1] * (alpha * a2 + beta * a2 * a2);
+    }
+    const R ox = R(1) - x[0], oy = R(1) - x[1];
+    return k * ox * ox + k * oy * oy;
+  }
+};
+
 // A user-energy plugin may also supply the hard-wall predicate (ME_REJECT_USER): Energy::reject(x).  Built-in
 // energies have none; the second overload answers "never reject" for them.
 template <class E, typename R, int D>
@@ -219,6 +241,71 @@ template <class E, typename R, int D>
 __device__ __forceinline__ bool energy_reject(const E &, const R (&)[D], long) {
   return false;
 }
+
+// ------------------------------------------------------------------------------------------------ energy ledger
+// The reference caches one energy per term and lets a group move re-evaluate only the terms registered for that group
+// (energy dictionaries, metropolis_engine.py:111-116, :214-221, :230-237); a single callable is the one term "total".
+// The ledger is the energy field: one row per term.  A GROUP kernel loads, re-evaluates, compares and stores only the
+// rows its group can change; step_all touches every row.  With one term this is exactly `e = E(x)`.
+template <class E, class = void>
+struct term_count { static constexpr int value = 1; };
+template <class E>
+struct term_count<E, std::void_t<decltype(E::kTerms)>> { static constexpr int value = E::kTerms; };
+
+template <typename R, class Energy, int GROUP>
+struct EnergyLedger {
+  static constexpr int T = term_count<Energy>::value;
+  R term[T];
+  static constexpr bool moves(int t) {
+    if constexpr (T == 1 || GROUP == GROUP_ALL) return true;
+    else return (Energy::term_groups(t) & (GROUP == GROUP_REAL ? 1u : 2u)) != 0u;
+  }
+  __device__ __forceinline__ void load(const Field<R> &fe, unsigned int coff) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      if (moves(t)) term[t] = fe.load(t, coff);
+  }
+  __device__ __forceinline__ void store(const Field<R> &fe, unsigned int coff) const {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      if (moves(t)) fe.store(t, coff, term[t]);
+  }
+  __device__ __forceinline__ R partial() const {   // sum of the cached terms the group can change
+    R s = 0;
+    bool first = true;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      if (moves(t)) {
+        s = first ? term[t] : s + term[t];
+        first = false;
+      }
+    return s;
+  }
+  // the same terms at the proposed state -> out[], returns their sum
+  template <int D>
+  __device__ __forceinline__ R propose(const Energy &en, const R (&xp)[D], R (&out)[T]) const {
+    if constexpr (T == 1) {
+      out[0] = en(xp);
+      return out[0];
+    } else {
+      R s = 0;
+      bool first = true;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        if (moves(t)) {
+          out[t] = en.term(t, xp);
+          s = first ? out[t] : s + out[t];
+          first = false;
+        }
+      return s;
+    }
+  }
+  __device__ __forceinline__ void commit(bool accept, const R (&out)[T]) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      if (moves(t)) term[t] = accept ? out[t] : term[t];
+  }
+};
 
 // ------------------------------------------------------------------------------------------------ k_step
 template <typename R>
@@ -277,14 +364,16 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   unsigned int wave_accepted = 0;
   bool bad_energy = false, bad_width = false;
   const long long stride = (long long)gridDim.x * blockDim.x;   // 64 threads per block, or 256 for fused sweeps
-  const Field<R> fx(a.x, a.n, D), fe(a.energy, a.n, 1), fw(a.width, a.n, MIXED ? 3 : 1);
+  using Ledger = EnergyLedger<R, Energy, GROUP>;
+  const Field<R> fx(a.x, a.n, D), fe(a.energy, a.n, Ledger::T), fw(a.width, a.n, MIXED ? 3 : 1);
   const Field<R> ffac(a.factor, a.n, CK == CK_PER_CHAIN ? NR * (NR + 1) / 2 + NC * NC : 0);
   for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
     R x[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) x[d] = fx.load(d, coff);
-    R e = fe.load(0, coff);
+    Ledger ledger;
+    ledger.load(fe, coff);
     // w: the width this launch adapts; w_r / w_c: the widths the real / complex proposals use
     R w = fw.load(MIXED ? GROUP : 0, coff);
     R w_r = w, w_c = w;
@@ -380,15 +469,16 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
       bool rejected = false;
       if (a.reject_kind == ME_REJECT_ABS_REAL0_GE) rejected = !(N_::abs_(xp[0]) < a.reject_bound);
       else if (a.reject_kind == ME_REJECT_USER) rejected = energy_reject(en, xp, 0);
-      const R e_new = en(xp);
-      const R diff = e_new - e;
+      R terms_new[Ledger::T];
+      const R e_new = ledger.propose(en, xp, terms_new);
+      const R diff = e_new - ledger.partial();
       bool accept = diff <= R(0);
       if (a.temp > R(0)) accept = accept || N_::uphill(u, diff, a.temp, a.inv_temp_log2e);
       accept = accept && !rejected;
       bad_energy |= (!rejected && !N_::finite(e_new));
 #pragma unroll
       for (int d = 0; d < D; ++d) x[d] = accept ? xp[d] : x[d];
-      e = accept ? e_new : e;
+      ledger.commit(accept, terms_new);
       // ---- Robbins-Monro width update (:429-456); step_all of a mixed engine mirrors it into both groups (:436-437)
       w = N_::adapt(w, accept, a.ratio, a.p, a.damping, a.up, a.down);
       if constexpr (GROUP == GROUP_ALL) w_r = w_c = w;
@@ -399,7 +489,7 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
     bad_width |= !(w > R(0));
 #pragma unroll
     for (int d = 0; d < D; ++d) fx.store(d, coff, x[d]);
-    fe.store(0, coff, e);
+    ledger.store(fe, coff);
     fw.store(MIXED ? GROUP : 0, coff, w);   // after a mixed step_all rows 1, 2 are implied equal to row 0 (host flag)
   }
   // acceptance tracking: ballot + popcount per sweep, then ONE plain read-modify-write of the wavefront's own
@@ -422,9 +512,17 @@ __global__ void __launch_bounds__(kStepThreads) k_init_energy(const R *xs, R *en
     R x[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) x[d] = xs[(long long)d * n + c];
-    const R e = en(x);
-    energy[c] = e;
-    if (!Num<R>::finite(e)) atomicOr(status, (unsigned int)ST_NONFINITE_ENERGY);
+    constexpr int T = term_count<Energy>::value;   // every term of the ledger (initialize_energy_dict, :152-155)
+    bool finite = true;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      R e;
+      if constexpr (T == 1) e = en(x);
+      else e = en.term(t, x);
+      energy[(long long)t * n + c] = e;
+      finite = finite && Num<R>::finite(e);
+    }
+    if (!finite) atomicOr(status, (unsigned int)ST_NONFINITE_ENERGY);
   }
 }
 

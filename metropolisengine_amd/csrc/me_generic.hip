@@ -177,24 +177,26 @@ __global__ void __launch_bounds__(kBlockThreads) k_sum_slots(const unsigned long
 
 template <typename R>
 __global__ void __launch_bounds__(kBlockThreads) k_trace(const R *x, const R *energy, const R *width, long long n, int d,
-                                                         int width_rows, long long n_traced, long long stride, double *out) {
+                                                         int n_terms, int width_rows, long long n_traced, long long stride,
+                                                         double *out) {
   const long long t = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
   if (t >= n_traced) return;
   const long long c = t * stride;
   for (int k = 0; k < d; ++k) out[(long long)k * n_traced + t] = (double)x[(long long)k * n + c];
-  out[(long long)d * n_traced + t] = (double)energy[c];
-  for (int r = 0; r < width_rows; ++r) out[(long long)(d + 1 + r) * n_traced + t] = (double)width[(long long)r * n + c];
+  for (int k = 0; k < n_terms; ++k) out[(long long)(d + k) * n_traced + t] = (double)energy[(long long)k * n + c];
+  for (int r = 0; r < width_rows; ++r)
+    out[(long long)(d + n_terms + r) * n_traced + t] = (double)width[(long long)r * n + c];
 }
 
-hipError_t launch_trace(const void *x, const void *energy, const void *width, long long n, int d, int width_rows,
-                        int dtype, long long n_traced, long long stride, double *out, hipStream_t stream) {
+hipError_t launch_trace(const void *x, const void *energy, const void *width, long long n, int d, int n_terms,
+                        int width_rows, int dtype, long long n_traced, long long stride, double *out, hipStream_t stream) {
   const dim3 grid((unsigned)((n_traced + kBlockThreads - 1) / kBlockThreads)), block(kBlockThreads);
   if (dtype == ME_F32)
     hipLaunchKernelGGL(k_trace<float>, grid, block, 0, stream, (const float *)x, (const float *)energy, (const float *)width,
-                       n, d, width_rows, n_traced, stride, out);
+                       n, d, n_terms, width_rows, n_traced, stride, out);
   else
     hipLaunchKernelGGL(k_trace<double>, grid, block, 0, stream, (const double *)x, (const double *)energy,
-                       (const double *)width, n, d, width_rows, n_traced, stride, out);
+                       (const double *)width, n, d, n_terms, width_rows, n_traced, stride, out);
   return hipGetLastError();
 }
 

@@ -82,6 +82,7 @@ struct KernelSet {
   int dtype, n_real, n_complex;
   bool per_chain_cov;  // measure can refresh per-chain factors / step can read them
   bool (*has_energy)(int energy_kind);
+  int (*energy_terms)(int energy_kind);   // rows of the energy ledger (1 unless the energy is a term dictionary)
   hipError_t (*step)(const StepLaunch &, hipStream_t);
   hipError_t (*magphase)(const StepLaunch &, hipStream_t);   // nullptr: no complex group / no per-chain covariance
   hipError_t (*measure)(const MeasureLaunch &, hipStream_t);
@@ -109,9 +110,9 @@ hipError_t launch_pool_reduce(const void *x, long long n, int n_real, int n_comp
 // blocks of the first reduction stage; partials must hold pool_reduce_blocks(...) * (1 + D + nr + nc + D(D+1)/2) doubles
 int pool_reduce_blocks(long long n, int n_real, int n_complex);
 // Time-series row of the traced chains (chain t*stride, t < n_traced): out[col][t] as doubles with columns
-// [params (d) | energy | widths (width_rows)]  -- what measure() appends in the reference (:350-356).
-hipError_t launch_trace(const void *x, const void *energy, const void *width, long long n, int d, int width_rows,
-                        int dtype, long long n_traced, long long stride, double *out, hipStream_t stream);
+// [params (d) | energy terms (n_terms) | widths (width_rows)]  -- what measure() appends in the reference (:350-356).
+hipError_t launch_trace(const void *x, const void *energy, const void *width, long long n, int d, int n_terms,
+                        int width_rows, int dtype, long long n_traced, long long stride, double *out, hipStream_t stream);
 // total[0] = sum of slots[0 .. n_slots)
 hipError_t launch_sum_slots(const unsigned long long *slots, long long n_slots, unsigned long long *total,
                             hipStream_t stream);

@@ -38,12 +38,31 @@ constexpr bool kLandau = (NR == 2 && NC == 1);
 constexpr bool kCylinder = (NR >= 1 && NC >= 1);
 
 #ifdef ME_USER_SOURCE
+#ifdef ME_USER_N_TERMS
+}  // namespace
+}  // namespace me
+// a term-wise plugin's total energy is the sum of its terms (calc_energy_total, metropolis_engine.py:158-162)
+template <typename R>
+__device__ __forceinline__ R me_user_energy(const R *x, const R *coef) {
+  R s = me_user_energy_term<R>(0, x, coef);
+#pragma unroll
+  for (int t = 1; t < ME_USER_N_TERMS; ++t) s += me_user_energy_term<R>(t, x, coef);
+  return s;
+}
+namespace me {
+namespace {
+#endif
 // Direct form: the user function is inlined into k_step (state stays in registers).
 template <typename R, int NR_, int NC_>
 struct EnergyUser {
   static constexpr int D = NR_ + 2 * NC_;
   const R *coef;
   __device__ __forceinline__ R operator()(const R (&x)[D]) const { return me_user_energy<R>(x, coef); }
+#ifdef ME_USER_N_TERMS
+  static constexpr int kTerms = ME_USER_N_TERMS;
+  static constexpr unsigned term_groups(int t) { return me_user_term_groups(t); }
+  __device__ __forceinline__ R term(int t, const R (&x)[D]) const { return me_user_energy_term<R>(t, x, coef); }
+#endif
 #ifdef ME_USER_HAS_REJECT
   __device__ __forceinline__ bool reject(const R (&x)[D]) const { return me_user_reject<R>(x, coef); }
 #endif
@@ -75,19 +94,27 @@ user_fn_t<R> load_user_fn() {
 }
 #endif
 
-bool has_energy(int kind) {
+// rows of the energy ledger for this kind (0: the kind is not in this kernel set)
+int energy_terms(int kind) {
 #ifdef ME_USER_SOURCE
-  return kind == ME_ENERGY_USER || kind == ME_ENERGY_USER_INDIRECT;
+#ifdef ME_USER_N_TERMS
+  if (kind == ME_ENERGY_USER) return ME_USER_N_TERMS;
+#else
+  if (kind == ME_ENERGY_USER) return 1;
+#endif
+  return kind == ME_ENERGY_USER_INDIRECT ? 1 : 0;
 #endif
   switch (kind) {
     case ME_ENERGY_ISO_QUAD:
-    case ME_ENERGY_DIAG_QUAD: return true;
-    case ME_ENERGY_DENSE_QUAD: return ME_DENSE != 0;
-    case ME_ENERGY_LANDAU_TOY: return kLandau;
-    case ME_ENERGY_CYLINDER: return kCylinder;
-    default: return false;
+    case ME_ENERGY_DIAG_QUAD: return 1;
+    case ME_ENERGY_DENSE_QUAD: return ME_DENSE != 0 ? 1 : 0;
+    case ME_ENERGY_LANDAU_TOY: return kLandau ? 1 : 0;
+    case ME_ENERGY_LANDAU_TERMS: return kLandau ? 2 : 0;
+    case ME_ENERGY_CYLINDER: return kCylinder ? 1 : 0;
+    default: return 0;
   }
 }
+bool has_energy(int kind) { return energy_terms(kind) > 0; }
 
 template <typename R>
 StepArgs<R> typed(const StepLaunch &l) {
@@ -242,6 +269,14 @@ hipError_t with_energy(int kind, const double *coef, int n_coef, const void *coe
       }
       return hipErrorInvalidValue;
     }
+    case ME_ENERGY_LANDAU_TERMS: {
+      if constexpr (kLandau) {
+        if (n_coef != 3) return hipErrorInvalidValue;
+        EnergyLandauTerms<R, NR, NC> en{(R)coef[0], (R)coef[1], (R)coef[2]};
+        return f(en);
+      }
+      return hipErrorInvalidValue;
+    }
     case ME_ENERGY_CYLINDER: {
       if constexpr (kCylinder) {
         if (n_coef != 3) return hipErrorInvalidValue;
@@ -328,10 +363,10 @@ constexpr size_t kFactorImageBytes = (NR == 64 && NC == 0) ? sizeof(unsigned int
 #else
 #define ME_PREPARE_FACTOR_F32 0, nullptr
 #endif
-const KernelSet kSetF32 = {ME_SET_NAME, ME_F32, NR, NC, ME_PER_CHAIN != 0, has_energy, step<float>,
+const KernelSet kSetF32 = {ME_SET_NAME, ME_F32, NR, NC, ME_PER_CHAIN != 0, has_energy, energy_terms, step<float>,
                            (NC > 0 && ME_PER_CHAIN) ? magphase<float> : nullptr, measure<float>, init_energy<float>,
                            ME_PREPARE_FACTOR_F32};
-const KernelSet kSetF64 = {ME_SET_NAME, ME_F64, NR, NC, ME_PER_CHAIN != 0, has_energy, step<double>,
+const KernelSet kSetF64 = {ME_SET_NAME, ME_F64, NR, NC, ME_PER_CHAIN != 0, has_energy, energy_terms, step<double>,
                            (NC > 0 && ME_PER_CHAIN) ? magphase<double> : nullptr, measure<double>, init_energy<double>,
                            0, nullptr};
 

@@ -52,7 +52,8 @@ __global__ void __launch_bounds__(kStepThreads) k_step_magphase(StepArgs<R> a, E
   unsigned int wave_accepted = 0;
   bool bad_energy = false, bad_width = false;
   const long long stride = (long long)gridDim.x * kStepThreads;
-  const Field<R> fx(a.x, a.n, D), fe(a.energy, a.n, 1), fw(a.width, a.n, MIXED ? 3 : 1), fcov(a.factor, a.n, P);
+  using Ledger = EnergyLedger<R, Energy, MIXED ? GROUP_COMPLEX : GROUP_ALL>;   // the complex group's terms (:183-189)
+  const Field<R> fx(a.x, a.n, D), fe(a.energy, a.n, Ledger::T), fw(a.width, a.n, MIXED ? 3 : 1), fcov(a.factor, a.n, P);
   for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
     R x[D], kdiag[NC];
@@ -60,7 +61,8 @@ __global__ void __launch_bounds__(kStepThreads) k_step_magphase(StepArgs<R> a, E
     for (int d = 0; d < D; ++d) x[d] = fx.load(d, coff);
 #pragma unroll
     for (int j = 0; j < NC; ++j) kdiag[j] = fcov.load(cdiag(PR, j), coff);
-    R e = fe.load(0, coff);
+    Ledger ledger;
+    ledger.load(fe, coff);
     R w = fw.load(WROW, coff);
     const unsigned long long gid = a.chain_offset + (unsigned long long)c;
 
@@ -69,15 +71,16 @@ __global__ void __launch_bounds__(kStepThreads) k_step_magphase(StepArgs<R> a, E
       bool rejected = false;
       if (a.reject_kind == ME_REJECT_ABS_REAL0_GE) rejected = !(N_::abs_(xp[0]) < a.reject_bound);
       else if (a.reject_kind == ME_REJECT_USER) rejected = energy_reject(en, xp, 0);
-      const R e_new = en(xp);
-      const R diff = e_new - e;
+      R terms_new[Ledger::T];
+      const R e_new = ledger.propose(en, xp, terms_new);
+      const R diff = e_new - ledger.partial();
       bool accept = diff <= R(0);
       if (a.temp > R(0)) accept = accept || N_::uphill(u, diff, a.temp, a.inv_temp_log2e);
       accept = accept && !rejected;
       bad_energy |= (!rejected && !N_::finite(e_new));
 #pragma unroll
       for (int d = NR; d < D; ++d) x[d] = accept ? xp[d] : x[d];
-      e = accept ? e_new : e;
+      ledger.commit(accept, terms_new);
       wave_accepted += (unsigned int)__popcll(__ballot(accept));
       return accept;
     };
@@ -147,7 +150,7 @@ __global__ void __launch_bounds__(kStepThreads) k_step_magphase(StepArgs<R> a, E
     bad_width |= !(w > R(0));
 #pragma unroll
     for (int d = NR; d < D; ++d) fx.store(d, coff, x[d]);
-    fe.store(0, coff, e);
+    ledger.store(fe, coff);
     fw.store(WROW, coff, w);
   }
   if ((threadIdx.x & 63) == 0 && wave_accepted) {

@@ -12,9 +12,11 @@ from . import _capi
 
 
 class EnergySpec:
-    """Base class: ``kind`` (me_energy_kind) and ``coefficients(nr, nc)`` (flat float64 array)."""
+    """Base class: ``kind`` (me_energy_kind), ``coefficients(nr, nc)`` (flat float64 array) and ``term_names`` -- the
+    keys of the reference's energy dictionary (metropolis_engine.py:111-118); a single function is ``("total",)``."""
     kind = None
     name = "energy"
+    term_names = ("total",)
 
     def coefficients(self, n_real, n_complex):
         raise NotImplementedError
@@ -60,11 +62,16 @@ class DenseQuadratic(EnergySpec):
 
 
 class LandauToy(EnergySpec):
-    """``k(1-x)^2 + k(1-y)^2 + x y (alpha |c|^2 + beta |c|^4)`` -- demo/toymodel_complex_and_real.py:17-29."""
-    kind = _capi.ENERGY_LANDAU_TOY
+    """``k(1-x)^2 + k(1-y)^2 + x y (alpha |c|^2 + beta |c|^4)`` -- demo/toymodel_complex_and_real.py:17-29.
 
-    def __init__(self, k=1.0, alpha=-1.0, beta=0.5):
+    ``terms=True`` is the form the demo actually passes (:31-33): the dictionary ``{"complex": {"field"}, "real":
+    {"field", "area"}, "all": {"field", "area"}}``.  The engine then keeps one ledger row per term, and a group step
+    re-evaluates and compares only its group's terms (metropolis_engine.py:214-221, :230-237)."""
+
+    def __init__(self, k=1.0, alpha=-1.0, beta=0.5, terms=False):
         self.k, self.alpha, self.beta = float(k), float(alpha), float(beta)
+        self.kind = _capi.ENERGY_LANDAU_TERMS if terms else _capi.ENERGY_LANDAU_TOY
+        self.term_names = ("field", "area") if terms else ("total",)
 
     def coefficients(self, n_real, n_complex):
         if (n_real, n_complex) != (2, 1):
@@ -92,10 +99,12 @@ class UserEnergy(EnergySpec):
     ``source`` is the HIP header defining ``me_user_energy``; it is compiled (hipcc, once per name and dimensions)
     around the engine's kernels into ``lib/libme_user_<name>_<nr>_<nc>.so`` and loaded with ``me_load_plugin``.
     ``indirect=True`` calls it through a ``__device__`` function pointer instead of inlining it.
+    ``term_names``: for a term-wise plugin (``ME_USER_N_TERMS`` in the source) the names of its terms, in order.
     """
 
-    def __init__(self, name, source=None, coefficients=(), indirect=False):
+    def __init__(self, name, source=None, coefficients=(), indirect=False, term_names=("total",)):
         self.name = name
+        self.term_names = tuple(term_names)
         self.source = source
         self.coeffs = np.asarray(coefficients, dtype=np.float64).ravel()
         self.kind = _capi.ENERGY_USER_INDIRECT if indirect else _capi.ENERGY_USER

@@ -116,7 +116,7 @@ class MetropolisEngine:
             self.params_names = ["param_" + str(i) for i in range(nr + nc)]
         self.observables_names = ["abs_param_" + str(i) for i in range(nr + nc)]        # :86-87
         self.observables_names.extend(["param_" + str(i) + "_squared" for i in range(nr)])
-        self.energy_term_names = ["total"]                                               # :118
+        self.energy_term_names = list(energy_functions.term_names)                       # :112-118
         self.df = None
 
         self._lib = _capi.load()
@@ -172,6 +172,11 @@ class MetropolisEngine:
             _capi.check(self._lib.me_load_plugin(build.build_dims(nr, nc).encode()))
         _capi.check(self._lib.me_create(ctypes.byref(cfg), ctypes.byref(handle)))
         self._handle = handle
+        n_terms = ctypes.c_int32()
+        _capi.check(self._lib.me_energy_terms(handle, ctypes.byref(n_terms)), handle)
+        if n_terms.value != len(self.energy_term_names):
+            raise ValueError("the energy has %d terms on the device but term_names=%r" %
+                             (n_terms.value, tuple(self.energy_term_names)))
         alpha, ratio, m = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
         _capi.check(self._lib.me_constants(handle, ctypes.byref(alpha), ctypes.byref(m), ctypes.byref(ratio)), handle)
         self.alpha, self.m, self.ratio = alpha.value, m.value, ratio.value               # :101-107
@@ -264,8 +269,12 @@ class MetropolisEngine:
         self._reject_spec = reject_fct
 
     def set_energy_function(self, energy_function):
-        raise NotImplementedError("pass the EnergySpec to the constructor; term dictionaries "
-                                  "(metropolis_engine.py:111-116) are not built yet")
+        raise NotImplementedError("the energy is compiled into the kernels: pass the EnergySpec (single function or "
+                                  "term dictionary) to the constructor")
+
+    def initialize_energy_dict(self):
+        """Re-evaluate every term of the energy ledger at the current state (metropolis_engine.py:152-155)."""
+        self._check(self._lib.me_recompute_energy(self._handle))
 
     def set_initial_sampling_width(self, sampling_width):
         self.group_sampling_width = sampling_width                                       # :148-149 (unused there too)
@@ -351,12 +360,16 @@ class MetropolisEngine:
 
     @property
     def energy_total(self):
-        e = self._get(_capi.FIELD_ENERGY)[:, 0]
+        e = self._get(_capi.FIELD_ENERGY).sum(axis=1)     # sum of the ledger's terms (:158-162)
         return float(e[0]) if self.n_chains == 1 else e
 
     @property
     def energy(self):
-        return {"total": self.energy_total}
+        """The energy ledger, ``{term name: value}`` (``self.energy``, :152-155); one entry ``"total"`` unless the
+        energy is a term dictionary."""
+        rows = self._get(_capi.FIELD_ENERGY)
+        return {name: (float(rows[0, t]) if self.n_chains == 1 else rows[:, t])
+                for t, name in enumerate(self.energy_term_names)}
 
     def _counters(self):
         step, meas = ctypes.c_uint64(), ctypes.c_uint64()
@@ -442,7 +455,8 @@ class MetropolisEngine:
     # ------------------------------------------------------------------ out of scope this round
     # ------------------------------------------------------------------ time series (:31-35, :350-356, :466-479)
     def trace(self):
-        """Recorded series as ``[n_measures, n_traced, D + 1 + n_widths]``: params, energy, widths per measure()."""
+        """Recorded series as ``[n_measures, n_traced, D + n_terms + n_widths]``: params, energy terms, widths per
+        measure()."""
         rows, cols, k = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         self._check(self._lib.me_trace_shape(self._handle, ctypes.byref(rows), ctypes.byref(cols), ctypes.byref(k)))
         out = np.empty((rows.value, cols.value, k.value), dtype=np.float64)
@@ -459,10 +473,11 @@ class MetropolisEngine:
         real = tr[:, :nr]
         cplx = tr[:, nr:nr + nc] + 1j * tr[:, nr + nc:d]
         obs = np.concatenate((np.abs(real), np.abs(cplx), real ** 2), axis=1)
-        widths = tr[:, d + 1:]
+        t = len(self.energy_term_names)
+        widths = tr[:, d + t:]
         w_real = widths[:, 1 if widths.shape[1] == 3 else 0] if nr else None
         w_cplx = widths[:, 2 if widths.shape[1] == 3 else 0] if nc else None
-        return real, cplx, obs, tr[:, d], w_real, w_cplx
+        return real, cplx, obs, tr[:, d:d + t], w_real, w_cplx
 
     @property
     def real_params_time_series(self):
@@ -478,7 +493,8 @@ class MetropolisEngine:
 
     @property
     def energy_time_series(self):
-        return {"total": list(self._series()[3])}
+        series = self._series()[3]
+        return {name: list(series[:, t]) for t, name in enumerate(self.energy_term_names)}            # :123
 
     @property
     def real_group_sampling_width_time_series(self):
@@ -498,7 +514,8 @@ class MetropolisEngine:
         cols = {}
         for i, name in enumerate(self.observables_names):
             cols[name] = obs[:, i]
-        cols["total_energy"] = energy       # the reference stores one column per energy term (:468-469)
+        for name in sorted(self.energy_term_names):    # one column per energy term (:468-469; the reference iterates a set)
+            cols[name + "_energy"] = energy[:, self.energy_term_names.index(name)]
         if nr:
             for i in range(nr):
                 cols[self.params_names[i]] = real[:, i]
