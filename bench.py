@@ -119,7 +119,7 @@ def other_configs(me, device, chains_log2):
     e4.time_steps(50, 1)
     ms = e4.time_steps(100, 1) / 100
     out["config4"] = {"chain_steps_per_s": (n // 2) / (ms * 1e-3), "ms_per_launch": ms, "chains": n // 2,
-                      "state_GBps": (8 * 64 + 16) * (n // 2) / (ms * 1e-3) / 1e9, "kernel": "k_step_dense64_mfma"}
+                      "state_GBps": (8 * 64 + 16) * (n // 2) / (ms * 1e-3) / 1e9, "kernel": "k_step_dense64_bf16x3"}
     del e4
     src = os.path.join(ROOT, "examples", "user_energy_cylinder.h")
     out["config5"] = protocol(me.MetropolisEngine(me.UserEnergy("cylinder", src, (1.0, 0.5, 1.0)),
