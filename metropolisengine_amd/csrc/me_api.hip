@@ -118,7 +118,7 @@ struct me_engine {
   unsigned long long step_index = 0, measure_count = 1;   // counters start at 1 (metropolis_engine.py:72-75)
   // device buffers (SoA: component-major, chain-minor)
   void *x = nullptr, *energy = nullptr, *width = nullptr, *mean = nullptr, *cov = nullptr, *obs_mean = nullptr;
-  void *factor = nullptr, *shared_factor = nullptr, *shared_full = nullptr, *shared_image = nullptr, *coef_dev = nullptr,
+  void *factor = nullptr, *shared_factor = nullptr, *shared_full = nullptr, *shared_image = nullptr, *energy_image = nullptr, *coef_dev = nullptr,
        *row_dev = nullptr;
   unsigned long long *accept_slots = nullptr, *accept_total = nullptr;
   long long n_slots = 0;
@@ -211,7 +211,7 @@ int upload_shared_factor(me_engine *e, const double *packed) {
       for (int j = 0; j <= i; ++j) full[(size_t)i * e->nr + j] = packed[i * (i + 1) / 2 + j];
     to_device_type(full.data(), full.size(), e->dtype, bytes);
     ME_HIP(e, hipMemcpy(e->shared_full, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
-    if (e->shared_image) ME_HIP(e, e->ks->prepare_factor(e->shared_full, e->shared_image, e->stream));
+    if (e->shared_image) ME_HIP(e, e->ks->prepare_matrix(e->shared_full, e->shared_image, e->stream));
   }
   return ME_OK;
 }
@@ -223,6 +223,7 @@ void fill_step_launch(me_engine *e, StepLaunch &l, int n_sweeps) {
   l.factor = e->cov_kind == CK_PER_CHAIN ? e->factor : e->shared_factor;
   l.factor_full = e->shared_full;
   l.factor_image = e->shared_image;
+  l.energy_image = e->energy_image;
   l.coef_device = e->coef_dev;
   l.coef_host = e->coef.data();
   l.n_coef = (int)e->coef.size();
@@ -253,7 +254,7 @@ void fill_step_launch(me_engine *e, StepLaunch &l, int n_sweeps) {
 void release(me_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  void *bufs[] = {e->x, e->energy, e->width, e->mean, e->cov, e->obs_mean, e->factor, e->shared_factor, e->shared_full, e->shared_image,
+  void *bufs[] = {e->x, e->energy, e->width, e->mean, e->cov, e->obs_mean, e->factor, e->shared_factor, e->shared_full, e->shared_image, e->energy_image,
                   e->coef_dev, e->row_dev, e->accept_slots, e->accept_total, e->status, e->pool_dev, e->pool_partials, e->trace_dev};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -381,7 +382,7 @@ int me_create(const me_config *c, me_engine **out) {
   }
   ME_CREATE_HIP(hipMalloc(&e->shared_factor, (size_t)e->p * es));
   if (e->nc == 0) ME_CREATE_HIP(hipMalloc(&e->shared_full, (size_t)e->nr * e->nr * es));
-  if (e->shared_full && ks->prepare_factor) ME_CREATE_HIP(hipMalloc(&e->shared_image, ks->factor_image_bytes));
+  if (e->shared_full && ks->prepare_matrix) ME_CREATE_HIP(hipMalloc(&e->shared_image, ks->matrix_image_bytes));
   ME_CREATE_HIP(hipMalloc(&e->row_dev, (size_t)std::max(std::max(e->d, e->p), e->nobs) * es));
   e->n_slots = (e->n + 63) / 64 + 8;   // one slot per wavefront of the largest grid any step kernel uses
   ME_CREATE_HIP(hipMalloc((void **)&e->accept_slots, (size_t)e->n_slots * sizeof(unsigned long long)));
@@ -398,6 +399,10 @@ int me_create(const me_config *c, me_engine **out) {
     to_device_type(e->coef.data(), e->coef.size(), e->dtype, bytes);
     ME_CREATE_HIP(hipMalloc(&e->coef_dev, bytes.size()));
     ME_CREATE_HIP(hipMemcpy(e->coef_dev, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+    if (e->energy_kind == ME_ENERGY_DENSE_QUAD && ks->prepare_matrix) {
+      ME_CREATE_HIP(hipMalloc(&e->energy_image, ks->matrix_image_bytes));
+      ME_CREATE_HIP(ks->prepare_matrix(e->coef_dev, e->energy_image, e->stream));
+    }
   }
 #undef ME_CREATE_HIP
 

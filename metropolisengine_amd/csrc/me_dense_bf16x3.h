@@ -133,8 +133,9 @@ __device__ __forceinline__ void stage_bf16_fragments(unsigned int *lds_frag, con
 
 // The dense-64 sweep on the bf16 matrix pipe.  Same chain-per-lane geometry, stream contract and epilogue as
 // k_step_dense64_mfma; the proposals x' are parked in LDS between their production and the dot product / commit.
-// CK_IDENTITY keeps A's fragments in LDS (24 KiB + 128 KiB of proposals).  CK_SHARED has no room left for the factor's
-// fragments, so A's stay in LDS and L's are read from a global image the launcher prepares (24 KiB, L1/L2-resident).
+// A's fragments live in LDS (24 KiB + 128 KiB of proposals), copied per block from the image that
+// k_dense64_bf16_fragments prepares once per engine.  CK_SHARED has no LDS left for the factor's fragments: L's are
+// read from its global image (24 KiB, L1/L2-resident).
 template <int CK>
 constexpr size_t dense64_bf16_lds_bytes() {
   return sizeof(float) * (kBf16FragWords + 64 * kDenseBlockThreads);
@@ -149,34 +150,62 @@ __global__ void k_dense64_bf16_fragments(const float *__restrict__ m, unsigned i
 }
 
 template <int CK>
-__global__ void __launch_bounds__(kDenseBlockThreads, 2) k_step_dense64_bf16x3(StepArgs<float> a, const float *__restrict__ amat,
+__global__ void __launch_bounds__(kDenseBlockThreads, 2) k_step_dense64_bf16x3(StepArgs<float> a,
+                                                                             const unsigned int *__restrict__ afrag,
                                                                              const unsigned int *lfrag) {
   constexpr int D = 64;
   using N_ = Num<float>;
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
   extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
   unsigned int *lds_a = smem_u;
   float *lds_xp = reinterpret_cast<float *>(smem_u + kBf16FragWords) + threadIdx.x;   // this lane's column, stride 512
-  stage_bf16_fragments(lds_a, amat);
-  __syncthreads();
 
   const int lane = threadIdx.x & 63;
   unsigned int wave_accepted = 0;
   bool bad_energy = false, bad_width = false;
   const long long stride = (long long)gridDim.x * kDenseBlockThreads;
   const Field<float> fx(a.x, a.n, D), fe(a.energy, a.n, 1), fw(a.width, a.n, 1);
-  // every lane stays active (MFMA and permlane need the whole wavefront): tail lanes shadow the last chain
-  for (long long base = (long long)blockIdx.x * kDenseBlockThreads + (threadIdx.x & ~63); base < a.n; base += stride) {
-    const long long c_raw = base + lane;
-    const bool live = c_raw < a.n;
-    const long long c = live ? c_raw : a.n - 1;
-    const unsigned int coff = (unsigned int)c * 4u;
-    float x[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) x[d] = fx.load(d, coff);
-    float e = fe.load(0, coff);
-    float w = fw.load(0, coff);
-    const unsigned long long gid = a.chain_offset + (unsigned long long)c;
 
+  // every lane stays active (MFMA and permlane need the whole wavefront): tail lanes shadow the last chain
+  long long base = (long long)blockIdx.x * kDenseBlockThreads + (threadIdx.x & ~63);
+  bool have = base < a.n;
+  bool live = false;
+  unsigned int coff = 0;
+  unsigned long long gid = 0;
+  float x[D], e = 0.0f, w = 0.0f;
+  // Loads are issued in the order the first sweep consumes them (width, then rows 0, 1, 2, ...): memory returns in
+  // order, so the s_waitcnt before the first use of row 4b can leave the later rows in flight behind the Philox
+  // work.  Left to the scheduler the rows were issued scrambled and the first use waited for (almost) all of them.
+  auto load_tile = [&]() {
+    const long long c_raw = base + lane;
+    live = c_raw < a.n;
+    const long long c = live ? c_raw : a.n - 1;
+    coff = (unsigned int)c * 4u;
+    gid = a.chain_offset + (unsigned long long)c;
+    w = fw.load(0, coff);
+    e = fe.load(0, coff);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      x[d] = fx.load(d, coff);
+      if ((d & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // A's fragment image (24 KiB, prepared once per engine by k_dense64_bf16_fragments) is requested first and the first
+  // tile's state right behind it: the image lands, goes to LDS and the block passes its barrier while the state rows
+  // are still arriving
+  static_assert(kBf16FragWords / 4 == 3 * kDenseBlockThreads, "three 16-byte pieces of the image per thread");
+  u32x4 image[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) image[k] = reinterpret_cast<const u32x4 *>(afrag)[k * kDenseBlockThreads + threadIdx.x];
+  __builtin_amdgcn_sched_barrier(0);
+  load_tile();   // unconditional (a wave past the end shadows the last chain): a branch here would make the
+                 // s_waitcnt in front of the LDS writes below wait for the tile as well
+#pragma unroll
+  for (int k = 0; k < 3; ++k) reinterpret_cast<u32x4 *>(lds_a)[k * kDenseBlockThreads + threadIdx.x] = image[k];
+  __syncthreads();
+
+  while (have) {
     for (int s = 0; s < a.n_sweeps; ++s) {
       const unsigned long long step = a.step_index + (unsigned long long)s;
       U4 ctr;
@@ -239,6 +268,9 @@ __global__ void __launch_bounds__(kDenseBlockThreads, 2) k_step_dense64_bf16x3(S
       fe.store(0, coff, e);
       fw.store(0, coff, w);
     }
+    base += stride;
+    have = base < a.n;
+    if (have) load_tile();
   }
   if (lane == 0 && wave_accepted) {
     unsigned long long *slot = a.accept_slots + (size_t)blockIdx.x * (kDenseBlockThreads / 64) + (threadIdx.x >> 6);
@@ -257,18 +289,29 @@ inline bool dense64_exact_fp32_mfma() {
   return on;
 }
 
-// Host launcher.  lfrag (CK_SHARED): the factor's fragment image made by k_dense64_bf16_fragments.
+// Host launcher.  afrag / lfrag (CK_SHARED): fragment images of A / the factor made by k_dense64_bf16_fragments.
 template <int CK>
-inline hipError_t launch_step_dense64_bf16x3(const StepArgs<float> &a, const float *amat, const unsigned int *lfrag,
+inline hipError_t launch_step_dense64_bf16x3(const StepArgs<float> &a, const unsigned int *afrag, const unsigned int *lfrag,
                                              int grid_blocks, hipStream_t stream) {
   static const hipError_t attr = hipFuncSetAttribute((const void *)k_step_dense64_bf16x3<CK>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                                      (int)dense64_bf16_lds_bytes<CK>());
   if (attr != hipSuccess) return attr;
+  // LDS admits one block per CU; two persistent blocks per CU (each striding over its tiles, the next tile's loads
+  // issued before the current one retires) beat one block per tile by 12 % at one sweep per launch (block start-up:
+  // image copy + barrier with nothing else resident) and tie when sweeps are fused.  tools/dev/time_dense64_grid.py
+  static const int two_per_cu = [] {
+    int device = 0, cus = 0;
+    if (hipGetDevice(&device) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0)
+      return 512;
+    return 2 * cus;
+  }();
   long long blocks = (a.n + kDenseBlockThreads - 1) / kDenseBlockThreads;
-  if (grid_blocks > 0 && blocks > grid_blocks) blocks = grid_blocks;
+  const long long cap = grid_blocks > 0 ? grid_blocks : two_per_cu;
+  if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(k_step_dense64_bf16x3<CK>, dim3((unsigned)blocks), dim3(kDenseBlockThreads),
-                     dense64_bf16_lds_bytes<CK>(), stream, a, amat, lfrag);
+                     dense64_bf16_lds_bytes<CK>(), stream, a, afrag, lfrag);
   return hipGetLastError();
 }
 

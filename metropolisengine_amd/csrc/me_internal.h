@@ -39,7 +39,8 @@ struct StepLaunch {
   void *x, *energy, *width;
   const void *factor;        // CK_PER_CHAIN: [P][N]; CK_SHARED: [P]
   const void *factor_full;   // CK_SHARED on pure-real engines: the same factor as a dense [nr][nr] row-major matrix
-  const void *factor_image;  // ... and as whatever KernelSet::prepare_factor made of it (nullptr without that hook)
+  const void *factor_image;  // ... and as whatever KernelSet::prepare_matrix made of it (nullptr without that hook)
+  const void *energy_image;  // ME_ENERGY_DENSE_QUAD: the coefficient matrix through the same hook (nullptr without it)
   const void *coef_device;   // energy coefficients in device memory (device dtype)
   const double *coef_host;   // same, host doubles
   int n_coef;
@@ -87,10 +88,11 @@ struct KernelSet {
   hipError_t (*magphase)(const StepLaunch &, hipStream_t);   // nullptr: no complex group / no per-chain covariance
   hipError_t (*measure)(const MeasureLaunch &, hipStream_t);
   hipError_t (*init_energy)(const EnergyLaunch &, hipStream_t);
-  // optional: turn the dense shared factor into a kernel-specific operand image (image_bytes of device memory,
-  // owned by the engine), run whenever the shared factor is uploaded
-  size_t factor_image_bytes;
-  hipError_t (*prepare_factor)(const void *factor_full, void *image, hipStream_t);
+  // optional: turn a dense [D][D] device matrix (the shared proposal factor, the dense energy's coefficients) into a
+  // kernel-specific operand image (matrix_image_bytes of device memory owned by the engine); run whenever the
+  // matrix is uploaded
+  size_t matrix_image_bytes;
+  hipError_t (*prepare_matrix)(const void *matrix, void *image, hipStream_t);
 };
 
 void register_kernel_set(const KernelSet *set);

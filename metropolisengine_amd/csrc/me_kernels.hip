@@ -193,10 +193,12 @@ hipError_t step_with(const StepLaunch &l, const Energy &en, hipStream_t stream) 
         return launch_step_dense64_mfma<CK_SHARED>(a, en.a, (const float *)l.factor_full, l.grid_blocks, stream);
       return hipErrorInvalidValue;
     }
+    if (!l.energy_image) return hipErrorInvalidValue;
     if (l.cov_kind == CK_IDENTITY)
-      return launch_step_dense64_bf16x3<CK_IDENTITY>(a, en.a, nullptr, l.grid_blocks, stream);
+      return launch_step_dense64_bf16x3<CK_IDENTITY>(a, (const unsigned int *)l.energy_image, nullptr, l.grid_blocks, stream);
     if (l.cov_kind == CK_SHARED && l.factor_image)
-      return launch_step_dense64_bf16x3<CK_SHARED>(a, en.a, (const unsigned int *)l.factor_image, l.grid_blocks, stream);
+      return launch_step_dense64_bf16x3<CK_SHARED>(a, (const unsigned int *)l.energy_image,
+                                                   (const unsigned int *)l.factor_image, l.grid_blocks, stream);
     return hipErrorInvalidValue;
   } else
 #endif
@@ -350,7 +352,7 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
 #define ME_SET_NAME nullptr
 #endif
 #if ME_DENSE && !defined(ME_USER_SOURCE)
-hipError_t prepare_factor_f32(const void *factor_full, void *image, hipStream_t stream) {
+hipError_t prepare_matrix_f32(const void *factor_full, void *image, hipStream_t stream) {
   if constexpr (NR == 64 && NC == 0) {
     hipLaunchKernelGGL(k_dense64_bf16_fragments<0>, dim3(1), dim3(256), 0, stream, (const float *)factor_full,
                        (unsigned int *)image);
@@ -358,14 +360,14 @@ hipError_t prepare_factor_f32(const void *factor_full, void *image, hipStream_t 
   }
   return hipSuccess;
 }
-constexpr size_t kFactorImageBytes = (NR == 64 && NC == 0) ? sizeof(unsigned int) * kBf16FragWords : 0;
-#define ME_PREPARE_FACTOR_F32 kFactorImageBytes, (kFactorImageBytes ? prepare_factor_f32 : nullptr)
+constexpr size_t kMatrixImageBytes = (NR == 64 && NC == 0) ? sizeof(unsigned int) * kBf16FragWords : 0;
+#define ME_PREPARE_MATRIX_F32 kMatrixImageBytes, (kMatrixImageBytes ? prepare_matrix_f32 : nullptr)
 #else
-#define ME_PREPARE_FACTOR_F32 0, nullptr
+#define ME_PREPARE_MATRIX_F32 0, nullptr
 #endif
 const KernelSet kSetF32 = {ME_SET_NAME, ME_F32, NR, NC, ME_PER_CHAIN != 0, has_energy, energy_terms, step<float>,
                            (NC > 0 && ME_PER_CHAIN) ? magphase<float> : nullptr, measure<float>, init_energy<float>,
-                           ME_PREPARE_FACTOR_F32};
+                           ME_PREPARE_MATRIX_F32};
 const KernelSet kSetF64 = {ME_SET_NAME, ME_F64, NR, NC, ME_PER_CHAIN != 0, has_energy, energy_terms, step<double>,
                            (NC > 0 && ME_PER_CHAIN) ? magphase<double> : nullptr, measure<double>, init_energy<double>,
                            0, nullptr};
