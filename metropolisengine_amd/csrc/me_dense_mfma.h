@@ -112,9 +112,9 @@ __device__ __forceinline__ void philox_two_rounds(U4 &c, uint32_t &k0, uint32_t 
     const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
     U4 n;
-    n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+    n.x = xor3((uint32_t)(p1 >> 32), c.y, k0);
     n.y = (uint32_t)p1;
-    n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+    n.z = xor3((uint32_t)(p0 >> 32), c.w, k1);
     n.w = (uint32_t)p0;
     c = n;
     k0 += 0x9E3779B9u;

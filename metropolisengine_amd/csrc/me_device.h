@@ -24,17 +24,20 @@ struct U4 {
 };
 
 // Philox4x32-10 (Salmon et al. 2011; the generator of hiprand's PHILOX4_32_10).  The key schedule is
-// wave-uniform and lives in scalar registers; each round is two 32x32->64 multiplies (v_mad_u64_u32) and
-// four xors.
+// wave-uniform and lives in scalar registers; each round is two 32x32->64 multiplies (v_mad_u64_u32) and two
+// three-input xors (gfx950's v_bitop3_b32 with truth table 0x96; hipcc emits two v_xor_b32 for `a ^ b ^ c`).
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
 __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
     U4 n;
-    n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+    n.x = xor3((uint32_t)(p1 >> 32), c.y, k0);
     n.y = (uint32_t)p1;
-    n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+    n.z = xor3((uint32_t)(p0 >> 32), c.w, k1);
     n.w = (uint32_t)p0;
     c = n;
     k0 += 0x9E3779B9u;
