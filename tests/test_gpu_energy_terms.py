@@ -119,3 +119,28 @@ def test_term_names_must_match_the_device_ledger():
     with pytest.raises(ValueError):
         me.MetropolisEngine(me.UserEnergy("landau_terms", src, (1.0, -1.0, 0.5)), None, [0.0, 0.0], [0j], temp=0.1,
                             n_chains=64)
+
+
+def test_magnitude_phase_and_checkpoint_with_terms():
+    """The magnitude-phase sampler compares the complex group's terms only (:183-189); in float64 its trajectory equals
+    the single-function engine's (the untouched "area" term cancels).  state_dict carries every ledger row."""
+    kw = dict(temp=0.1, n_chains=512, seed=5, dtype="f64", complex_sample_method="magnitude-phase")
+    terms = me.MetropolisEngine(me.LandauToy(1.0, -1.0, 0.5, terms=True), None, [0.3, 0.2], [0.4 + 0.1j], **kw)
+    total = me.MetropolisEngine(me.LandauToy(1.0, -1.0, 0.5), None, [0.3, 0.2], [0.4 + 0.1j], **kw)
+    for eng in (terms, total):
+        for _ in range(60):                    # > 50 measures: the covariance feeds the magnitude step
+            eng.step_real_group()
+            eng.step_complex_group()
+            eng.measure()
+    same = np.all(np.abs(terms._get(0) - total._get(0)) < 1e-9, axis=1)
+    assert same.mean() > 0.99                  # a flipped near-tie decision would show up as a diverged chain
+    assert np.allclose(terms.energy_total[same], total.energy_total[same], rtol=0, atol=1e-9)
+    state = terms.state_dict()
+    assert state["energy"].shape == (512, 2)
+    clone = me.MetropolisEngine(me.LandauToy(1.0, -1.0, 0.5, terms=True), None, [0.0, 0.0], [0j], **kw)
+    clone.load_state_dict(state)
+    for eng in (terms, clone):
+        eng.step_complex_group(3)
+        eng.step_all(2)
+    assert np.array_equal(terms._get(0), clone._get(0))
+    assert np.array_equal(terms._get(_capi.FIELD_ENERGY), clone._get(_capi.FIELD_ENERGY))
