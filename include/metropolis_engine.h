@@ -94,6 +94,15 @@ typedef enum me_field {
   ME_FIELD_FACTOR = 6    /* [P]  Cholesky factors used by the proposals (same packing; conj(K) for complex) */
 } me_field;
 
+/* me_config.flags */
+typedef enum me_flags {
+  ME_FLAG_TRACK_COVARIANCE = 1 /* parameter spaces whose per-chain matrix is too large for the factor kernels (more
+                                  than 160 packed entries, e.g. 64 real parameters) keep means and observables only
+                                  by default; with this flag measure() also maintains each chain's running covariance
+                                  (metropolis_engine.py:416-427) as statistics -- P*4 bytes per chain, read and
+                                  written once per measure().  Smaller spaces always track it. */
+} me_flags;
+
 typedef struct me_config {
   uint32_t abi_version; /* ME_ABI_VERSION */
   int32_t device_id;    /* HIP device ordinal */
@@ -111,7 +120,7 @@ typedef struct me_config {
   int32_t n_energy_coeffs;
   const double *energy_coeffs;
   int32_t reject_kind; /* me_reject_kind */
-  int32_t reserved0;
+  int32_t flags;       /* me_flags */
   double reject_bound;
   const double *initial_params;     /* [D], broadcast to every chain */
   const double *covariance_real;    /* [nr*nr] row-major or NULL = identity (metropolis_engine.py:63-66) */

@@ -13,6 +13,7 @@ ME_OK, ME_ERR_INVALID, ME_ERR_UNSUPPORTED, ME_ERR_HIP, ME_ERR_NUMERIC, ME_ERR_ST
 ME_F32, ME_F64 = 0, 1
 (ENERGY_ISO_QUAD, ENERGY_DIAG_QUAD, ENERGY_DENSE_QUAD, ENERGY_LANDAU_TOY, ENERGY_CYLINDER, ENERGY_USER,
  ENERGY_USER_INDIRECT, ENERGY_LANDAU_TERMS) = range(8)
+FLAG_TRACK_COVARIANCE = 1
 REJECT_NONE, REJECT_ABS_REAL0_GE, REJECT_USER = 0, 1, 2
 STEP_ALL, STEP_REAL_GROUP, STEP_COMPLEX_GROUP, STEP_COMPLEX_MAGNITUDE_PHASE = range(4)
 COV_REFERENCE, COV_FIXED, COV_POOLED = 0, 1, 2
@@ -30,7 +31,7 @@ class MeConfig(ctypes.Structure):
         ("cov_mode", ctypes.c_int32),
         ("temp", ctypes.c_double), ("target_acceptance", ctypes.c_double), ("sampling_width", ctypes.c_double),
         ("energy_kind", ctypes.c_int32), ("n_energy_coeffs", ctypes.c_int32), ("energy_coeffs", _dp),
-        ("reject_kind", ctypes.c_int32), ("reserved0", ctypes.c_int32), ("reject_bound", ctypes.c_double),
+        ("reject_kind", ctypes.c_int32), ("flags", ctypes.c_int32), ("reject_bound", ctypes.c_double),
         ("initial_params", _dp), ("covariance_real", _dp), ("covariance_complex", _dp),
         ("user_energy_name", ctypes.c_char_p),
     ]

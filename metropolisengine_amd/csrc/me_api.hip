@@ -176,7 +176,9 @@ int field_info(me_engine *e, int field, void **ptr, int *comps) {
     case ME_FIELD_MEAN: *ptr = e->mean; *comps = e->d; return ME_OK;
     case ME_FIELD_OBS_MEAN: *ptr = e->obs_mean; *comps = e->nobs; return ME_OK;
     case ME_FIELD_COV:
-      if (!e->cov) return fail(e, ME_ERR_UNSUPPORTED, "per-chain covariance is not compiled for these dimensions");
+      if (!e->cov)
+        return fail(e, ME_ERR_UNSUPPORTED, "the per-chain covariance of this parameter space is only kept on request "
+                                           "(me_config.flags: ME_FLAG_TRACK_COVARIANCE)");
       *ptr = e->cov; *comps = e->p; return ME_OK;
     case ME_FIELD_FACTOR:
       if (!e->factor) return fail(e, ME_ERR_UNSUPPORTED, "per-chain factors are not compiled for these dimensions");
@@ -376,10 +378,9 @@ int me_create(const me_config *c, me_engine **out) {
   ME_CREATE_HIP(hipMalloc(&e->width, n * e->width_rows * es));
   ME_CREATE_HIP(hipMalloc(&e->mean, n * e->d * es));
   ME_CREATE_HIP(hipMalloc(&e->obs_mean, n * e->nobs * es));
-  if (ks->per_chain_cov) {
+  if (ks->per_chain_cov || (ks->tracks_cov && (c->flags & ME_FLAG_TRACK_COVARIANCE)))
     ME_CREATE_HIP(hipMalloc(&e->cov, n * e->p * es));
-    ME_CREATE_HIP(hipMalloc(&e->factor, n * e->p * es));
-  }
+  if (ks->per_chain_cov) ME_CREATE_HIP(hipMalloc(&e->factor, n * e->p * es));
   ME_CREATE_HIP(hipMalloc(&e->shared_factor, (size_t)e->p * es));
   if (e->nc == 0) ME_CREATE_HIP(hipMalloc(&e->shared_full, (size_t)e->nr * e->nr * es));
   if (e->shared_full && ks->prepare_matrix) ME_CREATE_HIP(hipMalloc(&e->shared_image, ks->matrix_image_bytes));

@@ -134,6 +134,37 @@ struct Field {
   }
 };
 
+// A field that may exceed the 4 GiB a single descriptor can span (the per-chain covariance of a large parameter space:
+// 2 080 rows at 64 real parameters).  It is walked with a per-lane 64-bit pointer that moves by whole rows: begin(c)
+// points at row 0 of chain c, load/store(row) first step the pointer from the row it is on to `row` (after unrolling a
+// compile-time distance, one 64-bit add per row for the sequential walks of k_measure).  Addresses that depend on the
+// chain also keep the compiler from hoisting two thousand row bases out of the chain loop into spilled scalars.
+template <typename R>
+struct BigField {
+  R *base, *p;
+  long long n;
+  int cur;
+  __device__ __forceinline__ BigField(const R *b, long long n_, int) : base(const_cast<R *>(b)), p(nullptr), n(n_), cur(0) {}
+  __device__ __forceinline__ void begin(long long chain) {
+    p = base + chain;
+    cur = 0;
+  }
+  __device__ __forceinline__ void seek(int row) {
+    p += (long long)(row - cur) * n;
+    cur = row;
+  }
+  __device__ __forceinline__ R load(int row, unsigned int) {
+    seek(row);
+    return *p;
+  }
+  __device__ __forceinline__ void store(int row, unsigned int, R value) {
+    seek(row);
+    *p = value;
+  }
+};
+// packed sizes up to this are kept in registers by the per-chain factor kernels (build.py: MAX_PACKED_IN_REGISTERS)
+constexpr int kMaxPackedInRegisters = 160;
+
 // ------------------------------------------------------------------------------------------------ energies
 // An energy is a small by-value functor evaluated on the chain's register-resident state
 // x[D] = [real | Re z | Im z]; it stands in for the reference's Python callback (metropolis_engine.py:250).
@@ -612,7 +643,10 @@ __global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
   bool bad_pivot = false;
   const long long stride = (long long)gridDim.x * kStepThreads;
   const Field<R> fx(a.x, a.n, D), fw(a.width, a.n, (NR > 0 && NC > 0) ? 3 : 1), fmean(a.mean, a.n, D), fobs(a.obs_mean, a.n, NOBS);
-  const Field<R> fcov(a.cov, a.n, PER_CHAIN_COV ? P : 0), ffac(a.factor, a.n, PER_CHAIN_COV ? P : 0);
+  // large matrices are statistics only (no factors, FUSED = false) and may pass 4 GiB per field: BigField
+  using CovField = std::conditional_t<(P > kMaxPackedInRegisters), BigField<R>, Field<R>>;
+  CovField fcov(a.cov, a.n, PER_CHAIN_COV ? P : 0);
+  const Field<R> ffac(a.factor, a.n, (PER_CHAIN_COV && FUSED) ? P : 0);
   for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
     R x[D], delta[D];
@@ -641,6 +675,7 @@ __global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
         const R w_cplx = fw.load((MIXED && a.split_widths) ? 2 : 0, coff);
         const R eps = w_real * w_real * a.inv_i;
         const R eps_c = w_cplx * w_cplx * a.inv_i;
+        if constexpr (P > kMaxPackedInRegisters) fcov.begin(c);
         R m[P];
 #pragma unroll
         for (int i = 0; i < NR; ++i)

@@ -82,6 +82,8 @@ struct KernelSet {
   const char *user_name;  // nullptr for the built-in sets; the plugin's name for user-energy sets
   int dtype, n_real, n_complex;
   bool per_chain_cov;  // measure can refresh per-chain factors / step can read them
+  bool tracks_cov;     // measure can maintain the per-chain running covariance (always true with per_chain_cov;
+                       // alone: statistics only, for matrices too large for the factor kernels)
   bool (*has_energy)(int energy_kind);
   int (*energy_terms)(int energy_kind);   // rows of the energy ledger (1 unless the energy is a term dictionary)
   hipError_t (*step)(const StepLaunch &, hipStream_t);

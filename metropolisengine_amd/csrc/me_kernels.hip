@@ -24,6 +24,9 @@
 #ifndef ME_PER_CHAIN
 #define ME_PER_CHAIN 1
 #endif
+#ifndef ME_TRACK_COV
+#define ME_TRACK_COV 1   // k_measure can maintain the per-chain running covariance (streaming form when ME_PER_CHAIN=0)
+#endif
 #ifndef ME_MEASURE_FUSED_MAX_P
 #define ME_MEASURE_FUSED_MAX_P 56   // largest packed size whose Cholesky is fused into k_measure ((2,7): 52 fused; (16,0): 136 split)
 #endif
@@ -334,9 +337,10 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
   a.write_factor = l.write_factor;
   // small packed matrices: one fused launch; large ones: streaming update, then the factor kernel (see k_measure)
   constexpr int P = NR * (NR + 1) / 2 + NC * NC;
-  constexpr bool kFused = P <= ME_MEASURE_FUSED_MAX_P;
+  constexpr bool kFused = ME_PER_CHAIN != 0 && P <= ME_MEASURE_FUSED_MAX_P;
   const dim3 grid(grid_for(l.n, l.grid_blocks)), block(kStepThreads);
-  hipLaunchKernelGGL((k_measure<R, NR, NC, ME_PER_CHAIN != 0, kFused>), grid, block, 0, stream, a);
+  if (l.cov) hipLaunchKernelGGL((k_measure<R, NR, NC, (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0), kFused>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((k_measure<R, NR, NC, false, false>), grid, block, 0, stream, a);
 #if ME_PER_CHAIN
   if constexpr (!kFused) {
     if (l.update_cov && l.write_factor)
@@ -365,10 +369,10 @@ constexpr size_t kMatrixImageBytes = (NR == 64 && NC == 0) ? sizeof(unsigned int
 #else
 #define ME_PREPARE_MATRIX_F32 0, nullptr
 #endif
-const KernelSet kSetF32 = {ME_SET_NAME, ME_F32, NR, NC, ME_PER_CHAIN != 0, has_energy, energy_terms, step<float>,
+const KernelSet kSetF32 = {ME_SET_NAME, ME_F32, NR, NC, ME_PER_CHAIN != 0, (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0), has_energy, energy_terms, step<float>,
                            (NC > 0 && ME_PER_CHAIN) ? magphase<float> : nullptr, measure<float>, init_energy<float>,
                            ME_PREPARE_MATRIX_F32};
-const KernelSet kSetF64 = {ME_SET_NAME, ME_F64, NR, NC, ME_PER_CHAIN != 0, has_energy, energy_terms, step<double>,
+const KernelSet kSetF64 = {ME_SET_NAME, ME_F64, NR, NC, ME_PER_CHAIN != 0, (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0), has_energy, energy_terms, step<double>,
                            (NC > 0 && ME_PER_CHAIN) ? magphase<double> : nullptr, measure<double>, init_energy<double>,
                            0, nullptr};
 

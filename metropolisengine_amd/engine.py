@@ -8,7 +8,8 @@ marshals arguments and unpacks results.  Differences from the reference, all for
  * ``energy_functions`` is an :class:`~metropolisengine_amd.energy.EnergySpec`, not a Python callable;
    ``reject_condition`` is a :class:`~metropolisengine_amd.energy.RejectSpec`.  (The reference silently drops a
    ``reject_condition`` given to the constructor -- SURVEY.md quirk Q6; here it is honoured.)
- * keyword-only extras: ``n_chains``, ``seed``, ``dtype``, ``device``, ``chain_offset``, ``cov_mode``.
+ * keyword-only extras: ``n_chains``, ``seed``, ``dtype``, ``device``, ``chain_offset``, ``cov_mode``, ``trace_chains``,
+   ``trace_stride``, ``track_covariance``.
  * with ``n_chains == 1`` attributes have the reference's shapes and ``step_all()`` returns a bool; with more
    chains they gain a leading chain axis and ``step_all()`` returns ``None`` (it stays asynchronous).
  * randomness is a seeded counter-based Philox stream per global chain id instead of numpy's global state.
@@ -66,7 +67,7 @@ class MetropolisEngine:
                  initial_complex_params=None, sampling_width=0.05, covariance_matrix_real=None,
                  covariance_matrix_complex=None, params_names=None, target_acceptance=.3, temp=0,
                  complex_sample_method="multivariate-gaussian", *, n_chains=1, seed=0, dtype="f32", device=0,
-                 chain_offset=0, cov_mode="reference", trace_chains=None, trace_stride=1):
+                 chain_offset=0, cov_mode="reference", trace_chains=None, trace_stride=1, track_covariance=False):
         if initial_real_params is None and initial_complex_params is None:
             print("must give list containing  at least one value for initial real or complex parameters")
             raise ValueError("no initial parameters")                                    # metropolis_engine.py:37-39
@@ -136,6 +137,9 @@ class MetropolisEngine:
             raise ValueError("cov_mode must be one of %s" % sorted(_COV_MODES))
         cfg.cov_mode = _COV_MODES[cov_mode]
         self.cov_mode = cov_mode
+        # parameter spaces beyond the factor kernels (> 160 packed matrix entries, e.g. 64 real parameters) keep the
+        # per-chain running covariance only on request: P floats per chain, read and written once per measure()
+        cfg.flags = _capi.FLAG_TRACK_COVARIANCE if track_covariance else 0
         cfg.temp = float(temp)
         cfg.target_acceptance = float(target_acceptance)
         cfg.sampling_width = float(sampling_width)

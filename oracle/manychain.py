@@ -25,12 +25,13 @@ from .reference_chain import ADAPTATION_FLOOR, MEASURES_BEFORE_COVARIANCE, adapt
 class ManyChainOracle:
     def __init__(self, nr, nc, energy, n_chains, seed=0, temp=0.0, initial_real_params=None,
                  initial_complex_params=None, sampling_width=0.05, target_acceptance=0.3, chain_offset=0,
-                 reject=None, covariance_matrix_real=None, covariance_matrix_complex=None):
+                 reject=None, covariance_matrix_real=None, covariance_matrix_complex=None, adapt_shape=True):
         if nr + nc == 0:
             raise ValueError("need at least one real or complex parameter")
         assert temp is not None and temp >= 0
         self.nr, self.nc, self.dim = nr, nc, nr + 2 * nc
         self.n_chains = n_chains
+        self.adapt_shape = adapt_shape     # False: the proposal shape stays the initial matrix (engine cov_mode="fixed")
         self.energy_fn = energy
         self.reject_fn = reject
         self.seed = seed
@@ -195,7 +196,8 @@ class ManyChainOracle:
                                        - n / (n - 1) * np.einsum("ni,nj->nij", mu, mu.conj())
                                        + np.einsum("ni,nj->nij", z, z.conj()) / (n - 1)
                                        + eps[:, None, None] * np.identity(nc)))
-            self._refresh_factors()
+            if self.adapt_shape:
+                self._refresh_factors()
         self.observables_mean = self.observables_mean * ((n - 1) / n) + self.observables() / n
 
     # ------------------------------------------------------------------ pooled moments
