@@ -134,34 +134,6 @@ struct Field {
   }
 };
 
-// A field that may exceed the 4 GiB a single descriptor can span (the per-chain covariance of a large parameter space:
-// 2 080 rows at 64 real parameters).  It is walked with a per-lane 64-bit pointer that moves by whole rows: begin(c)
-// points at row 0 of chain c, load/store(row) first step the pointer from the row it is on to `row` (after unrolling a
-// compile-time distance, one 64-bit add per row for the sequential walks of k_measure).  Addresses that depend on the
-// chain also keep the compiler from hoisting two thousand row bases out of the chain loop into spilled scalars.
-template <typename R>
-struct BigField {
-  R *base, *p;
-  long long n;
-  int cur;
-  __device__ __forceinline__ BigField(const R *b, long long n_, int) : base(const_cast<R *>(b)), p(nullptr), n(n_), cur(0) {}
-  __device__ __forceinline__ void begin(long long chain) {
-    p = base + chain;
-    cur = 0;
-  }
-  __device__ __forceinline__ void seek(int row) {
-    p += (long long)(row - cur) * n;
-    cur = row;
-  }
-  __device__ __forceinline__ R load(int row, unsigned int) {
-    seek(row);
-    return *p;
-  }
-  __device__ __forceinline__ void store(int row, unsigned int, R value) {
-    seek(row);
-    *p = value;
-  }
-};
 // packed sizes up to this are kept in registers by the per-chain factor kernels (build.py: MAX_PACKED_IN_REGISTERS)
 constexpr int kMaxPackedInRegisters = 160;
 
@@ -643,10 +615,12 @@ __global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
   bool bad_pivot = false;
   const long long stride = (long long)gridDim.x * kStepThreads;
   const Field<R> fx(a.x, a.n, D), fw(a.width, a.n, (NR > 0 && NC > 0) ? 3 : 1), fmean(a.mean, a.n, D), fobs(a.obs_mean, a.n, NOBS);
-  // large matrices are statistics only (no factors, FUSED = false) and may pass 4 GiB per field: BigField
-  using CovField = std::conditional_t<(P > kMaxPackedInRegisters), BigField<R>, Field<R>>;
-  CovField fcov(a.cov, a.n, PER_CHAIN_COV ? P : 0);
+  // Large matrices (P > kMaxPackedInRegisters) are statistics only (no factors, FUSED = false) and take the streaming
+  // path below; their field may pass the 4 GiB one descriptor spans and is walked with a 64-bit pointer instead.
+  constexpr bool STREAM = PER_CHAIN_COV && P > kMaxPackedInRegisters;
+  const Field<R> fcov(a.cov, a.n, (PER_CHAIN_COV && !STREAM) ? P : 0);
   const Field<R> ffac(a.factor, a.n, (PER_CHAIN_COV && FUSED) ? P : 0);
+  __shared__ R s_delta[STREAM ? D : 1][kStepThreads];
   for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
     R x[D], delta[D];
@@ -654,7 +628,8 @@ __global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
     for (int d = 0; d < D; ++d) {
       x[d] = fx.load(d, coff);
       const R mu = fmean.load(d, coff);
-      delta[d] = x[d] - mu;
+      if constexpr (STREAM) s_delta[d][threadIdx.x] = x[d] - mu;   // parked in LDS, see the streaming path below
+      else delta[d] = x[d] - mu;
       fmean.store(d, coff, mu * a.keep + x[d] * a.inv_i);   // :404-410
     }
     // observables [|x_r|, |z_c|, x_r^2] and their running mean (:458-463, :412-414)
@@ -675,7 +650,44 @@ __global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
         const R w_cplx = fw.load((MIXED && a.split_widths) ? 2 : 0, coff);
         const R eps = w_real * w_real * a.inv_i;
         const R eps_c = w_cplx * w_cplx * a.inv_i;
-        if constexpr (P > kMaxPackedInRegisters) fcov.begin(c);
+        if constexpr (STREAM) {
+          // delta is parked in LDS (lane-linear, conflict-free) so that the walk over the packed entries can be a
+          // ROLLED loop: unrolled, 2 080 entries are ~100 KB of code and the kernel becomes instruction-fetch bound.
+          // One 64-bit pointer per lane steps by whole rows (the packed order is exactly the loop order).
+          R *p = a.cov + c;
+          for (int i = 0; i < NR; ++i) {
+            const R di = s_delta[i][threadIdx.x];
+            int j = 0;
+            // batches of 8 entries: all loads first (a store to p[.] would otherwise fence the next load, the compiler
+            // cannot prove the rows distinct), then the updates
+            for (; j + 8 <= i; j += 8) {
+              R v[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) v[u] = p[u * a.n];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) p[u * a.n] = v[u] * a.cov_keep + di * s_delta[j + u][threadIdx.x] * a.inv_i;
+              p += 8 * a.n;
+            }
+            for (; j < i; ++j) {
+              *p = *p * a.cov_keep + di * s_delta[j][threadIdx.x] * a.inv_i;
+              p += a.n;
+            }
+            *p = *p * a.cov_keep + di * di * a.inv_i + eps;
+            p += a.n;
+          }
+          for (int i = 0; i < NC; ++i) {
+            const R ai = s_delta[NR + i][threadIdx.x], bi = s_delta[NR + NC + i][threadIdx.x];
+#pragma unroll 4
+            for (int j = 0; j < i; ++j) {
+              const R aj = s_delta[NR + j][threadIdx.x], bj = s_delta[NR + NC + j][threadIdx.x];
+              p[0] = p[0] * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
+              p[a.n] = p[a.n] * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
+              p += 2 * a.n;
+            }
+            *p = *p * a.cov_keep + (ai * ai + bi * bi) * a.inv_i + eps_c;
+            p += a.n;
+          }
+        } else {
         R m[P];
 #pragma unroll
         for (int i = 0; i < NR; ++i)
@@ -713,6 +725,7 @@ __global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
             for (int k = 0; k < P; ++k) ffac.store(k, coff, m[k]);
           }
         }
+        }   // !STREAM
       }
     }
   }
