@@ -19,6 +19,44 @@ __global__ void __launch_bounds__(64) k_rmw(float *f, long long n, float a) {
   }
 }
 
+// the k_step pattern: all rows of a chain loaded first, then all stored
+template <int R, bool TILE>
+__global__ void __launch_bounds__(64) k_load_then_store(float *f, long long n, float a) {
+  const long long stride = (long long)gridDim.x * 64;
+  for (long long c = (long long)blockIdx.x * 64 + threadIdx.x; c < n; c += stride) {
+    float *p = TILE ? f + (c >> 6) * (long long)R * 64 + (c & 63) : f + c;
+    const long long step = TILE ? 64 : n;
+    float v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = p[r * step];
+#pragma unroll
+    for (int r = 0; r < R; ++r) p[r * step] = v[r] * a + 1.0f;
+  }
+}
+
+template <int R, bool TILE>
+void run_ls(long long n) {
+  float *f;
+  if (hipMalloc(&f, sizeof(float) * n * R) != hipSuccess) { printf("alloc failed\n"); return; }
+  (void)hipMemset(f, 0, sizeof(float) * n * R);
+  const int grid = (int)((n + 63) / 64);
+  hipEvent_t t0, t1;
+  (void)hipEventCreate(&t0);
+  (void)hipEventCreate(&t1);
+  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_load_then_store<R, TILE>), dim3(grid), dim3(64), 0, 0, f, n, 0.5f);
+  (void)hipEventRecord(t0);
+  const int reps = 200;
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_load_then_store<R, TILE>), dim3(grid), dim3(64), 0, 0, f, n, 0.5f);
+  (void)hipEventRecord(t1);
+  (void)hipEventSynchronize(t1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, t0, t1);
+  ms /= reps;
+  printf("load-then-store R=%3d n=2^%d %-15s %8.4f ms  %6.0f GB/s\n", R, (int)__builtin_ctzll(n),
+         TILE ? "tile-major" : "component-major", ms, 8.0 * n * R / ms / 1e6);
+  (void)hipFree(f);
+}
+
 template <int R, bool TILE>
 void run(long long n) {
   float *f;
@@ -43,6 +81,12 @@ void run(long long n) {
 }
 
 int main() {
+  run_ls<18, false>(1 << 20);
+  run_ls<18, true>(1 << 20);
+  run_ls<18, false>(1 << 21);
+  run_ls<18, true>(1 << 21);
+  run_ls<18, false>(1 << 22);
+  run_ls<18, true>(1 << 22);
   run<18, false>(1 << 22);
   run<18, true>(1 << 22);
   run<200, false>(1 << 20);
