@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 
 template <int R, bool TILE>
 __global__ void __launch_bounds__(64) k_rmw(float *f, long long n, float a) {
@@ -32,6 +33,46 @@ __global__ void __launch_bounds__(64) k_load_then_store(float *f, long long n, f
 #pragma unroll
     for (int r = 0; r < R; ++r) p[r * step] = v[r] * a + 1.0f;
   }
+}
+
+// 16-byte accesses: [tile][row/4][lane][4] ("packets" of four rows of one chain adjacent in memory)
+template <int R4>
+__global__ void __launch_bounds__(64) k_load_then_store_x4(float4 *f, long long n, float a) {
+  const long long stride = (long long)gridDim.x * 64;
+  for (long long c = (long long)blockIdx.x * 64 + threadIdx.x; c < n; c += stride) {
+    float4 *p = f + (c >> 6) * (long long)R4 * 64 + (c & 63);
+    float4 v[R4];
+#pragma unroll
+    for (int r = 0; r < R4; ++r) v[r] = p[r * 64];
+#pragma unroll
+    for (int r = 0; r < R4; ++r) {
+      v[r].x = v[r].x * a + 1.0f; v[r].y = v[r].y * a + 1.0f; v[r].z = v[r].z * a + 1.0f; v[r].w = v[r].w * a + 1.0f;
+      p[r * 64] = v[r];
+    }
+  }
+}
+
+template <int R4>
+void run_x4(long long n) {
+  float4 *f;
+  if (hipMalloc(&f, sizeof(float4) * n * R4) != hipSuccess) { printf("alloc failed\n"); return; }
+  (void)hipMemset(f, 0, sizeof(float4) * n * R4);
+  const int grid = (int)((n + 63) / 64);
+  hipEvent_t t0, t1;
+  (void)hipEventCreate(&t0);
+  (void)hipEventCreate(&t1);
+  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_load_then_store_x4<R4>), dim3(grid), dim3(64), 0, 0, f, n, 0.5f);
+  (void)hipEventRecord(t0);
+  const int reps = 200;
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_load_then_store_x4<R4>), dim3(grid), dim3(64), 0, 0, f, n, 0.5f);
+  (void)hipEventRecord(t1);
+  (void)hipEventSynchronize(t1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, t0, t1);
+  ms /= reps;
+  printf("load-then-store R=%3d n=2^%d %-15s %8.4f ms  %6.0f GB/s\n", 4 * R4, (int)__builtin_ctzll(n), "tile-major x4", ms,
+         32.0 * n * R4 / ms / 1e6);
+  (void)hipFree(f);
 }
 
 template <int R, bool TILE>
@@ -81,12 +122,18 @@ void run(long long n) {
 }
 
 int main() {
+  run_ls<20, false>(1 << 20);
+  run_ls<20, true>(1 << 20);
+  run_x4<5>(1 << 20);
+  run_x4<5>(1 << 22);
+  run_ls<20, true>(1 << 22);
   run_ls<18, false>(1 << 20);
   run_ls<18, true>(1 << 20);
   run_ls<18, false>(1 << 21);
   run_ls<18, true>(1 << 21);
   run_ls<18, false>(1 << 22);
   run_ls<18, true>(1 << 22);
+  if (getenv("LAYOUT_PROBE_ALL")) {
   run<18, false>(1 << 22);
   run<18, true>(1 << 22);
   run<200, false>(1 << 20);
@@ -95,5 +142,6 @@ int main() {
   run<2080, true>(1 << 17);
   run<2080, false>(1 << 19);
   run<2080, true>(1 << 19);
+  }
   return 0;
 }
