@@ -20,13 +20,19 @@ AMAT = _M @ _M.T / 64 + np.identity(64)
 ASYM = AMAT + 0.05 * np.triu(np.random.default_rng(6).standard_normal((64, 64)), 1)   # not symmetric: catches a transposed operand
 
 
-@pytest.mark.parametrize("matrix", [AMAT, ASYM], ids=["spd", "asymmetric"])
-def test_mfma_energy_one_step_vs_oracle(matrix):
+# a matrix with entries spread over six decades exercises the three-piece split of both operands
+WIDE = AMAT * np.exp(np.random.default_rng(7).uniform(-7.0, 7.0, size=(64, 64)))
+WIDE = 0.5 * (WIDE + WIDE.T) + 40.0 * np.diag(np.abs(WIDE).sum(axis=1)) / 64
+
+
+@pytest.mark.parametrize("matrix,temp", [(AMAT, 1.0), (ASYM, 1.0), (AMAT * 3e4, 3e4), (WIDE, 50.0)],
+                         ids=["spd", "asymmetric", "scaled", "wide-range"])
+def test_mfma_energy_one_step_vs_oracle(matrix, temp):
     n, seed = 4096 + 37, 11          # ragged tail: the last wavefront has shadow lanes
     x0 = list(np.linspace(-0.3, 0.3, 64))
-    eng = me.MetropolisEngine(me.DenseQuadratic(matrix), None, x0, None, temp=1.0, n_chains=n, seed=seed,
+    eng = me.MetropolisEngine(me.DenseQuadratic(matrix), None, x0, None, temp=temp, n_chains=n, seed=seed,
                               sampling_width=0.1, cov_mode="fixed")
-    ora = ManyChainOracle(64, 0, energies.dense_quadratic(64, 0, matrix), n, seed=seed, temp=1.0,
+    ora = ManyChainOracle(64, 0, energies.dense_quadratic(64, 0, matrix), n, seed=seed, temp=temp,
                           initial_real_params=x0, sampling_width=0.1)
     assert np.allclose(eng.energy_total, ora.energy, rtol=2e-6)
     eng.step_all()
@@ -86,4 +92,4 @@ def test_fp32_mfma_variant_in_child_process():
                           "one_step or f64_kernel", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
                          timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
-    assert "3 passed" in res.stdout
+    assert "5 passed" in res.stdout
