@@ -63,3 +63,26 @@ def test_rows_beyond_4_gib_are_addressed_correctly():
     assert np.all(np.isfinite(first)) and not np.array_equal(first[0], a[0])
     diag = unpack_real_block(a, 64)[:, np.arange(64), np.arange(64)]
     assert np.all(diag > 0)
+
+
+def test_streamed_covariance_with_a_complex_block_f64():
+    """1 real + 13 complex parameters: 170 packed entries, just past the factor kernels; the kernel set is compiled on
+    demand (build_dims) and the Hermitian block goes through the same streaming path."""
+    nr, nc, n, seed = 1, 13, 37, 21
+    a, b = (0.7,), tuple(0.5 + 0.25 * j for j in range(nc))
+    real0, cplx0 = [0.1], [0.05 * (j + 1) * np.exp(0.3j * j) for j in range(nc)]
+    eng = me.MetropolisEngine(me.DiagQuadratic(a, b), None, real0, cplx0, temp=1.0, n_chains=n, seed=seed, dtype="f64",
+                              sampling_width=0.2, cov_mode="fixed", track_covariance=True)
+    ora = ManyChainOracle(nr, nc, energies.diag_quadratic(nr, nc, a, b), n, seed=seed, temp=1.0,
+                          initial_real_params=real0, initial_complex_params=cplx0, sampling_width=0.2,
+                          adapt_shape=False)
+    for _ in range(57):
+        eng.step_all(3)
+        ora.step(3)
+        eng.measure()
+        ora.measure()
+    assert np.allclose(eng._get(_capi.FIELD_PARAMS), ora.x, rtol=0, atol=1e-9)
+    assert np.allclose(eng.covariance_matrix_real, ora.cov_real, rtol=0, atol=1e-9)
+    assert np.allclose(eng.covariance_matrix_complex, ora.cov_complex, rtol=0, atol=1e-9)
+    assert np.abs(ora.cov_complex[0] - np.identity(nc)).max() > 1e-3
+    assert eng.accept_stats() == (ora.accepted, ora.proposed)
