@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -14,13 +15,23 @@
 namespace me {
 
 // ------------------------------------------------------------------------------------------------ registry
+// Kernel sets register themselves from static constructors (the library's own and those of plugins loaded later, possibly
+// while other threads create engines): one mutex guards the list.
 static std::vector<const KernelSet *> &registry() {
   static std::vector<const KernelSet *> sets;
   return sets;
 }
-void register_kernel_set(const KernelSet *set) { registry().push_back(set); }
+static std::mutex &registry_mutex() {
+  static std::mutex m;
+  return m;
+}
+void register_kernel_set(const KernelSet *set) {
+  std::lock_guard<std::mutex> lock(registry_mutex());
+  registry().push_back(set);
+}
 static bool is_user_kind(int kind) { return kind == ME_ENERGY_USER || kind == ME_ENERGY_USER_INDIRECT; }
 const KernelSet *find_kernel_set(int dtype, int n_real, int n_complex, int energy_kind, const char *user_name) {
+  std::lock_guard<std::mutex> lock(registry_mutex());
   for (const KernelSet *s : registry()) {
     if (s->dtype != dtype || s->n_real != n_real || s->n_complex != n_complex || !s->has_energy(energy_kind)) continue;
     if (is_user_kind(energy_kind)) {
@@ -31,6 +42,7 @@ const KernelSet *find_kernel_set(int dtype, int n_real, int n_complex, int energ
   return nullptr;
 }
 bool has_dims(int dtype, int n_real, int n_complex) {
+  std::lock_guard<std::mutex> lock(registry_mutex());
   for (const KernelSet *s : registry())
     if (s->dtype == dtype && s->n_real == n_real && s->n_complex == n_complex && !s->user_name) return true;
   return false;
