@@ -138,7 +138,7 @@ struct me_engine {
   int width_rows = 1;           // 3 for mixed engines: [sampling_width, real group, complex group]
   bool widths_synced = true;    // mixed engines: rows 1, 2 are implied equal to row 0 (state after a step_all)
   unsigned int *status = nullptr;
-  double *pool_dev = nullptr, *pool_partials = nullptr;
+  double *pool_dev = nullptr, *pool_partials = nullptr, *pool_host = nullptr;   // pool_host: pinned
   // time-series trace of a few chains (the reference's per-measure appends, :350-356)
   double *trace_dev = nullptr;
   long long trace_chains = 0, trace_stride = 1, trace_rows = 0, trace_capacity = 0;
@@ -272,6 +272,7 @@ void release(me_engine *e) {
                   e->coef_dev, e->row_dev, e->accept_slots, e->accept_total, e->status, e->pool_dev, e->pool_partials, e->trace_dev};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
+  if (e->pool_host) (void)hipHostFree(e->pool_host);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -402,6 +403,7 @@ int me_create(const me_config *c, me_engine **out) {
   ME_CREATE_HIP(hipMalloc((void **)&e->accept_total, sizeof(unsigned long long)));
   ME_CREATE_HIP(hipMalloc((void **)&e->status, sizeof(unsigned int)));
   ME_CREATE_HIP(hipMalloc((void **)&e->pool_dev, sizeof(double) * (size_t)moments_size(e->nr, e->nc)));
+  ME_CREATE_HIP(hipHostMalloc((void **)&e->pool_host, sizeof(double) * (size_t)moments_size(e->nr, e->nc), hipHostMallocDefault));
   ME_CREATE_HIP(hipMalloc((void **)&e->pool_partials,
                           sizeof(double) * (size_t)pool_reduce_blocks(e->n, e->nr, e->nc) *
                               (size_t)(1 + e->d + e->nr + e->nc + e->d * (e->d + 1) / 2)));
@@ -834,24 +836,35 @@ int me_pooled_moments_size(me_engine *e, int64_t *n_doubles) {
   return ME_OK;
 }
 
-int me_pooled_moments_device(me_engine *e, void *device_out, int64_t n_doubles) {
-  if (!e || !device_out) return ME_ERR_INVALID;
+namespace {
+// k_pool_reduce + k_pool_finish into `device_out`, enqueued on the engine's stream (no synchronisation)
+int enqueue_pooled_moments(me_engine *e, void *device_out, int64_t n_doubles) {
   if (n_doubles != moments_size(e->nr, e->nc)) return fail(e, ME_ERR_INVALID, "wrong pooled-moment buffer length");
   ME_HIP(e, hipSetDevice(e->device));
-  ME_HIP(e, launch_sum_slots(e->accept_slots, e->n_slots, e->accept_total, e->stream));
-  hipError_t err = launch_pool_reduce(e->x, e->n, e->nr, e->nc, e->dtype, e->accept_total, (double)e->proposed,
-                                      e->pool_partials, (double *)device_out, e->stream);
+  hipError_t err = launch_pool_reduce(e->x, e->n, e->nr, e->nc, e->dtype, e->accept_slots, e->n_slots,
+                                      (double)e->proposed, e->pool_partials, (double *)device_out, e->stream);
   if (err == hipErrorInvalidValue) return fail(e, ME_ERR_UNSUPPORTED, "pooled moments: dimension too large for the reduction kernel");
   ME_HIP(e, err);
+  return ME_OK;
+}
+}  // namespace
+
+int me_pooled_moments_device(me_engine *e, void *device_out, int64_t n_doubles) {
+  if (!e || !device_out) return ME_ERR_INVALID;
+  int rc = enqueue_pooled_moments(e, device_out, n_doubles);
+  if (rc != ME_OK) return rc;
   ME_HIP(e, hipStreamSynchronize(e->stream));
   return ME_OK;
 }
 
 int me_pooled_moments(me_engine *e, double *host_out, int64_t n_doubles) {
   if (!e || !host_out) return ME_ERR_INVALID;
-  int rc = me_pooled_moments_device(e, e->pool_dev, n_doubles);
+  int rc = enqueue_pooled_moments(e, e->pool_dev, n_doubles);
   if (rc != ME_OK) return rc;
-  ME_HIP(e, hipMemcpy(host_out, e->pool_dev, sizeof(double) * (size_t)n_doubles, hipMemcpyDeviceToHost));
+  // through a pinned staging buffer: one asynchronous copy behind the kernels, one wait
+  ME_HIP(e, hipMemcpyAsync(e->pool_host, e->pool_dev, sizeof(double) * (size_t)n_doubles, hipMemcpyDeviceToHost, e->stream));
+  ME_HIP(e, hipStreamSynchronize(e->stream));
+  std::memcpy(host_out, e->pool_host, sizeof(double) * (size_t)n_doubles);
   return ME_OK;
 }
 

@@ -105,32 +105,59 @@ __global__ void __launch_bounds__(kBlockThreads) k_pool_reduce(const R *x, long 
     if (active[k]) partials[(long long)blockIdx.x * n_entries + tid + k * kBlockThreads] = acc[k];
 }
 
-// Stage 2: 64 entries x 4 block-slices per workgroup; a thread sums every 4th block's partial of its entry (consecutive
-// lanes read consecutive entries: coalesced; 8 independent loads in flight), the slices meet in LDS, and the total
-// goes where the public layout wants it.
-__global__ void __launch_bounds__(kBlockThreads) k_pool_finish(const double *partials, int n_blocks, int nr, int nc,
-                                                               const unsigned long long *accepted_total, double proposed,
-                                                               double *out) {
-  __shared__ double part[4][64];
+// Stage 2: 64 entries x 16 block-slices per workgroup; a thread sums every 16th block's partial of its entry (consecutive
+// lanes read consecutive entries: coalesced; 8 independent loads in flight), the slices meet in LDS in a fixed order,
+// and the total goes where the public layout wants it.  One extra workgroup (the last) sums the per-wavefront
+// acceptance slots, so the pooled path needs no separate k_sum_slots launch.
+constexpr int kFinishThreads = 1024, kFinishSlices = kFinishThreads / 64;
+__global__ void __launch_bounds__(kFinishThreads) k_pool_finish(const double *partials, int n_blocks, int nr, int nc,
+                                                                const unsigned long long *slots, long long n_slots,
+                                                                double proposed, double *out) {
   const int d = nr + 2 * nc;
   const int n_aug = d + nr + nc;
   const int n_pair = d * (d + 1) / 2;
   const int n_entries = 1 + n_aug + n_pair;
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  if (blockIdx.x == gridDim.x - 1) {   // acceptance slots -> accepted, proposed
+    __shared__ unsigned long long wave_sum[kFinishSlices];
+    unsigned long long s = 0;
+    long long i = threadIdx.x;
+    for (; i + 7 * kFinishThreads < n_slots; i += 8 * kFinishThreads) {
+      unsigned long long v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = slots[i + u * kFinishThreads];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; i < n_slots; i += kFinishThreads) s += slots[i];
+#pragma unroll
+    for (int w = 32; w > 0; w >>= 1) s += __shfl_xor(s, w, 64);
+    if (lane == 0) wave_sum[slice] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long t = 0;
+#pragma unroll
+      for (int w = 0; w < kFinishSlices; ++w) t += wave_sum[w];
+      const long long size = moments_size(nr, nc);
+      out[size - 2] = (double)t;
+      out[size - 1] = proposed;
+    }
+    return;
+  }
+  __shared__ double part[kFinishSlices][64];
   const int e = blockIdx.x * 64 + lane;
   double s = 0.0;
   if (e < n_entries) {
 #pragma unroll 8
-    for (int b = slice; b < n_blocks; b += 4) s += partials[(long long)b * n_entries + e];
+    for (int b = slice; b < n_blocks; b += kFinishSlices) s += partials[(long long)b * n_entries + e];
   }
   part[slice][lane] = s;
   __syncthreads();
   if (slice != 0) return;
-  s = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+  s = 0.0;
+#pragma unroll
+  for (int w = 0; w < kFinishSlices; ++w) s += part[w][lane];
   if (e == 0) {
-    const long long size = moments_size(nr, nc);
-    out[size - 2] = (double)accepted_total[0];
-    out[size - 1] = proposed;
     out[0] = s;                                            // n
   } else if (e <= n_aug) {
     const int r = e - 1;
@@ -230,9 +257,9 @@ int pool_reduce_blocks(long long n, int nr, int nc) {
   return (int)(tiles < cap ? (tiles < 1 ? 1 : tiles) : cap);
 }
 
-hipError_t launch_pool_reduce(const void *x, long long n, int nr, int nc, int dtype,
-                              const unsigned long long *accepted_total, double proposed, double *partials,
-                              double *out_device, hipStream_t stream) {
+hipError_t launch_pool_reduce(const void *x, long long n, int nr, int nc, int dtype, const unsigned long long *slots,
+                              long long n_slots, double proposed, double *partials, double *out_device,
+                              hipStream_t stream) {
   const int d = nr + 2 * nc;
   const int n_aug = d + nr + nc;
   const int n_entries = 1 + n_aug + d * (d + 1) / 2;
@@ -259,8 +286,8 @@ hipError_t launch_pool_reduce(const void *x, long long n, int nr, int nc, int dt
   }
   err = hipGetLastError();
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL(k_pool_finish, dim3((unsigned)((n_entries + 63) / 64)), dim3(kBlockThreads),
-                     0, stream, (const double *)partials, blocks, nr, nc, accepted_total, proposed, out_device);
+  hipLaunchKernelGGL(k_pool_finish, dim3((unsigned)((n_entries + 63) / 64 + 1)), dim3(kFinishThreads), 0, stream,
+                     (const double *)partials, blocks, nr, nc, slots, n_slots, proposed, out_device);
   return hipGetLastError();
 }
 

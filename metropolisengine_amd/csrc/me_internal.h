@@ -106,10 +106,10 @@ bool has_dims(int dtype, int n_real, int n_complex);
 // dst[r*n + c] = row_values[r] for r < rows, c < n   (broadcast one chain's vector to all chains)
 hipError_t launch_broadcast_rows(void *dst, const void *row_values, int rows, long long n, int dtype,
                                  hipStream_t stream);
-// Ensemble sums (see me_pooled_moments in the public header).  out must hold moments_size doubles and is
-// zeroed by the launcher; accepted_total is a device scalar (from launch_sum_slots), proposed is host-known.
+// Ensemble sums (see me_pooled_moments in the public header).  out must hold moments_size doubles; `slots` are the
+// per-wavefront acceptance counters (summed by the finishing kernel), proposed is host-known.
 hipError_t launch_pool_reduce(const void *x, long long n, int n_real, int n_complex, int dtype,
-                              const unsigned long long *accepted_total, double proposed, double *partials,
+                              const unsigned long long *slots, long long n_slots, double proposed, double *partials,
                               double *out_device, hipStream_t stream);
 // blocks of the first reduction stage; partials must hold pool_reduce_blocks(...) * (1 + D + nr + nc + D(D+1)/2) doubles
 int pool_reduce_blocks(long long n, int n_real, int n_complex);

@@ -108,3 +108,13 @@ def pooled_factor(covariance, n_real, n_complex, jitter=0.0):
                 packed.extend((lc[i, j].real, lc[i, j].imag))
             packed.append(lc[i, i].real)
     return np.asarray(packed, dtype=np.float64)
+
+
+def adapt_pooled_shape(engine, group=None, jitter=0.0):
+    """The many-chain counterpart of the reference's per-chain covariance adaptation (metropolis_engine.py:416-427 feeding
+    :261-302): pool the ensemble covariance over all ranks (one all-reduce), factor it and install it as the proposal
+    shape every chain shares (``cov_mode="pooled"``).  Returns the pooled statistics."""
+    stats = pooled_statistics(engine, group)
+    engine.set_shared_factor(pooled_factor(stats["covariance"], engine.num_real_params, engine.num_complex_params,
+                                           jitter=jitter))
+    return stats

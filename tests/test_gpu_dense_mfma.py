@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import metropolisengine_amd as me
-from metropolisengine_amd.distributed import moments_to_statistics, pooled_factor
+from metropolisengine_amd.distributed import adapt_pooled_shape, moments_to_statistics
 from oracle import energies
 from oracle.manychain import ManyChainOracle
 
@@ -60,7 +60,8 @@ def test_mfma_stationary_covariance_identity_and_pooled():
     assert np.all(np.abs(st["covariance"] - want) < tol)
     rate_identity = st["acceptance_rate"]
     # pooled_shared: one Cholesky factor of the pooled covariance shapes every chain's proposals (L g on the MFMA)
-    eng.set_shared_factor(pooled_factor(st["covariance"], 64, 0))
+    pooled = adapt_pooled_shape(eng)                        # pooled_statistics -> pooled_factor -> set_shared_factor
+    assert np.allclose(pooled["covariance"], st["covariance"])
     eng.step_all(2000)
     st2 = moments_to_statistics(eng.pooled_moments(), 64, 0)
     assert np.all(np.abs(st2["covariance"] - want) < tol)
