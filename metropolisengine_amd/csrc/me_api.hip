@@ -842,7 +842,8 @@ int enqueue_pooled_moments(me_engine *e, void *device_out, int64_t n_doubles) {
   if (n_doubles != moments_size(e->nr, e->nc)) return fail(e, ME_ERR_INVALID, "wrong pooled-moment buffer length");
   ME_HIP(e, hipSetDevice(e->device));
   hipError_t err = launch_pool_reduce(e->x, e->n, e->nr, e->nc, e->dtype, e->accept_slots, e->n_slots,
-                                      (double)e->proposed, e->pool_partials, (double *)device_out, e->stream);
+                                      (double)e->proposed, e->pool_partials, (double *)device_out, e->stream,
+                                      e->ks->pool_stage1);
   if (err == hipErrorInvalidValue) return fail(e, ME_ERR_UNSUPPORTED, "pooled moments: dimension too large for the reduction kernel");
   ME_HIP(e, err);
   return ME_OK;

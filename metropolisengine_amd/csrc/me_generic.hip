@@ -259,7 +259,8 @@ int pool_reduce_blocks(long long n, int nr, int nc) {
 
 hipError_t launch_pool_reduce(const void *x, long long n, int nr, int nc, int dtype, const unsigned long long *slots,
                               long long n_slots, double proposed, double *partials, double *out_device,
-                              hipStream_t stream) {
+                              hipStream_t stream,
+                              hipError_t (*stage1)(const void *, long long, double *, int, hipStream_t)) {
   const int d = nr + 2 * nc;
   const int n_aug = d + nr + nc;
   const int n_entries = 1 + n_aug + d * (d + 1) / 2;
@@ -269,7 +270,10 @@ hipError_t launch_pool_reduce(const void *x, long long n, int nr, int nc, int dt
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const int blocks = pool_reduce_blocks(n, nr, nc);
   hipError_t err;
-  if (dtype == ME_F32) {
+  if (stage1) {
+    err = stage1(x, n, partials, blocks, stream);
+    if (err != hipSuccess) return err;
+  } else if (dtype == ME_F32) {
     if (lds > 64 * 1024) {
       err = hipFuncSetAttribute((const void *)k_pool_reduce<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (err != hipSuccess) return err;

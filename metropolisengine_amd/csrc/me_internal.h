@@ -95,6 +95,9 @@ struct KernelSet {
   // matrix is uploaded
   size_t matrix_image_bytes;
   hipError_t (*prepare_matrix)(const void *matrix, void *image, hipStream_t);
+  // optional: a dimension-specific first stage of the pooled-moment reduction writing partials[row][entry] for
+  // n_rows rows in k_pool_finish's entry order (nullptr: the generic k_pool_reduce)
+  hipError_t (*pool_stage1)(const void *x, long long n, double *partials, int n_rows, hipStream_t);
 };
 
 void register_kernel_set(const KernelSet *set);
@@ -110,7 +113,8 @@ hipError_t launch_broadcast_rows(void *dst, const void *row_values, int rows, lo
 // per-wavefront acceptance counters (summed by the finishing kernel), proposed is host-known.
 hipError_t launch_pool_reduce(const void *x, long long n, int n_real, int n_complex, int dtype,
                               const unsigned long long *slots, long long n_slots, double proposed, double *partials,
-                              double *out_device, hipStream_t stream);
+                              double *out_device, hipStream_t stream,
+                              hipError_t (*stage1)(const void *, long long, double *, int, hipStream_t) = nullptr);
 // blocks of the first reduction stage; partials must hold pool_reduce_blocks(...) * (1 + D + nr + nc + D(D+1)/2) doubles
 int pool_reduce_blocks(long long n, int n_real, int n_complex);
 // Time-series row of the traced chains (chain t*stride, t < n_traced): out[col][t] as doubles with columns

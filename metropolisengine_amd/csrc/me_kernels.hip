@@ -7,6 +7,7 @@
 #include "me_device.h"
 #include "me_dense_mfma.h"
 #include "me_dense_bf16x3.h"
+#include "me_pool_gram64.h"
 #include "me_magphase.h"
 
 // User-energy plugin mode: -DME_USER_SOURCE='"file"' -DME_USER_NAME='"name"' compiles the SAME kernels around a
@@ -365,16 +366,17 @@ hipError_t prepare_matrix_f32(const void *factor_full, void *image, hipStream_t 
   return hipSuccess;
 }
 constexpr size_t kMatrixImageBytes = (NR == 64 && NC == 0) ? sizeof(unsigned int) * kBf16FragWords : 0;
-#define ME_PREPARE_MATRIX_F32 kMatrixImageBytes, (kMatrixImageBytes ? prepare_matrix_f32 : nullptr)
+#define ME_PREPARE_MATRIX_F32 kMatrixImageBytes, (kMatrixImageBytes ? prepare_matrix_f32 : nullptr), \
+                              ((NR == 64 && NC == 0) ? launch_pool_gram64 : nullptr)
 #else
-#define ME_PREPARE_MATRIX_F32 0, nullptr
+#define ME_PREPARE_MATRIX_F32 0, nullptr, nullptr
 #endif
 const KernelSet kSetF32 = {ME_SET_NAME, ME_F32, NR, NC, ME_PER_CHAIN != 0, (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0), has_energy, energy_terms, step<float>,
                            (NC > 0 && ME_PER_CHAIN) ? magphase<float> : nullptr, measure<float>, init_energy<float>,
                            ME_PREPARE_MATRIX_F32};
 const KernelSet kSetF64 = {ME_SET_NAME, ME_F64, NR, NC, ME_PER_CHAIN != 0, (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0), has_energy, energy_terms, step<double>,
                            (NC > 0 && ME_PER_CHAIN) ? magphase<double> : nullptr, measure<double>, init_energy<double>,
-                           0, nullptr};
+                           0, nullptr, nullptr};
 
 struct Registrar {
   Registrar() {

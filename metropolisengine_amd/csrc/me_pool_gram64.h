@@ -1,0 +1,113 @@
+// Stage 1 of the pooled-moment reduction for 64 real parameters (float32) on the matrix cores: the 64 x 64 second-moment
+// matrix of a 64-chain tile is the Gram product X X^T (X = [parameter][chain]), 2 080 + 129 entries that the generic
+// k_pool_reduce (me_generic.hip) walks entry by entry through LDS (237 us at 2^19 chains).  Here one wavefront owns a
+// tile: lanes load their chains' rows (coalesced), park the tile in a wavefront-private LDS slab with an odd pitch, and
+// read it back TRANSPOSED as MFMA operands -- lane l of v_mfma_f32_32x32x2_f32 holds A[row l&31][k = l>>5], i.e.
+// parameter l&31 of chain 2s + (l>>5); B's map is the mirror image, so A's fragment of block nb IS B's operand and only
+// the three lower blocks (0,0), (1,0), (1,1) are formed (96 MFMAs per tile).  fp32 products and sums inside a tile, fp64
+// across tiles -- the same numerics class as the generic kernel -- and the per-wavefront partial sums go to
+// partials[wavefront][entry] in the order k_pool_finish expects.  2^19 chains: 56 us (MFMA loop ~23, loads ~11, row sums
+// ~4, the rest LDS staging and the fp64 flush), against 237 us for the generic kernel.
+#pragma once
+
+#include "me_dense_mfma.h"
+
+namespace me {
+
+constexpr int kGramWaves = 2;            // wavefronts per workgroup, each with its own LDS slab (2 x 16.6 KB)
+constexpr int kGramPitch = 65;           // floats per parameter row (odd: column reads of 32 rows hit 32 banks)
+
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(64 * kGramWaves) k_pool_gram64(const float *__restrict__ x, long long n,
+                                                                 double *__restrict__ partials, int n_rows) {
+  constexpr int D = 64;
+  constexpr int n_aug = 2 * D;                   // sum x_i, sum |x_i|
+  constexpr int n_entries = 1 + n_aug + D * (D + 1) / 2;
+  __shared__ float slab[kGramWaves][D * kGramPitch];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row_id = blockIdx.x * kGramWaves + wave;            // this wavefront's row of partials
+  if (row_id >= n_rows) return;
+  float *tile = slab[wave];
+  const int r31 = lane & 31, h = lane >> 5;
+
+  double g[3][16];                               // blocks (0,0), (1,0), (1,1) in MFMA accumulator layout
+  double sum_x = 0.0, sum_abs = 0.0, count = 0.0;   // lane l: parameter l
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[b][r] = 0.0;
+
+  const long long n_tiles = (n + 63) / 64;
+  // One wavefront per SIMD is resident (1 024 partial rows), so nothing else hides the load latency: the next tile's 64
+  // rows are requested before the current tile is reduced (first version without the prefetch: 184 us at 2^19 chains).
+  float next[D];
+  auto request = [&](long long t) {
+    const long long c = t * 64 + lane;
+    const bool live = t < n_tiles && c < n;
+    const long long cc = live ? c : 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const float v = x[(long long)d * n + cc];
+      next[d] = live ? v : 0.0f;
+    }
+  };
+  request(row_id);
+  for (long long t = row_id; t < n_tiles; t += n_rows) {
+    // chain `lane`'s 64 parameters -> LDS column `lane` (lane-linear writes)
+#pragma unroll
+    for (int d = 0; d < D; ++d) tile[d * kGramPitch + lane] = next[d];
+    request(t + n_rows);
+    count += (double)(n - t * 64 < 64 ? n - t * 64 : 64);
+    // row sums: lane l walks parameter l's row (bank = (l + col) mod 64: conflict-free)
+    float sx = 0.0f, sa = 0.0f;
+#pragma unroll 16
+    for (int col = 0; col < 64; ++col) {
+      const float v = tile[lane * kGramPitch + col];
+      sx += v;
+      sa += __builtin_fabsf(v);
+    }
+    sum_x += (double)sx;
+    sum_abs += (double)sa;
+    // Gram blocks: k step s covers chains 2s, 2s+1
+    f32x16 acc[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) {
+      const float lo = tile[r31 * kGramPitch + 2 * s + h];            // parameters 0..31 of chain 2s + h
+      const float hi = tile[(32 + r31) * kGramPitch + 2 * s + h];     // parameters 32..63
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(lo, lo, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(hi, lo, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(hi, hi, acc[2], 0, 0, 0);
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[b][r] += (double)acc[b][r];
+  }
+
+  double *out = partials + (long long)row_id * n_entries;
+  if (lane == 0) out[0] = count;
+  out[1 + lane] = sum_x;
+  out[1 + D + lane] = sum_abs;
+  // accumulator register r of lane l is element (row acc_row(r) + 4h, column l & 31) of its block
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const int i0 = b == 0 ? 0 : 32, j0 = b == 2 ? 32 : 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + acc_row(r) + 4 * h, j = j0 + r31;
+      if (i >= j) out[1 + n_aug + i * (i + 1) / 2 + j] = g[b][r];
+    }
+  }
+}
+
+inline hipError_t launch_pool_gram64(const void *x, long long n, double *partials, int n_rows, hipStream_t stream) {
+  hipLaunchKernelGGL(k_pool_gram64<0>, dim3((unsigned)((n_rows + kGramWaves - 1) / kGramWaves)), dim3(64 * kGramWaves), 0, stream,
+                     (const float *)x, n, partials, n_rows);
+  return hipGetLastError();
+}
+
+}  // namespace me

@@ -90,7 +90,30 @@ def test_fp32_mfma_variant_in_child_process():
         pytest.skip("already the fp32 MFMA variant")
     env = dict(os.environ, METROPOLIS_DENSE64_FP32_MFMA="1")
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
-                          "one_step or f64_kernel", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
+                          "one_step or f64_kernel or gram", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
                          timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
-    assert "5 passed" in res.stdout
+    assert "6 passed" in res.stdout
+
+
+def test_pooled_moments_gram_kernel_matches_numpy():
+    """64 real parameters pool their second moments with the matrix-core Gram kernel (me_pool_gram64.h); the result must be
+    the plain sums over the chains' current states (ragged last tile, several tiles per wavefront)."""
+    from metropolisengine_amd.distributed import moments_size
+    for n in (64 * 3 + 5, (1 << 16) + 64 * 7 + 9):
+        eng = me.MetropolisEngine(me.DenseQuadratic(AMAT), None, list(np.linspace(-0.5, 0.5, 64)), None, temp=1.0,
+                                  n_chains=n, seed=13, sampling_width=0.2, cov_mode="fixed")
+        eng.step_all(40)
+        x = eng._get(0)
+        m = eng.pooled_moments()
+        assert m.shape == (moments_size(64, 0),)
+        acc, prop = eng.accept_stats()
+        assert m[0] == n and m[-2] == acc and m[-1] == prop
+        assert np.allclose(m[1:65], x.sum(axis=0), rtol=5e-6, atol=1e-3)
+        second = x.T @ x
+        assert np.allclose(m[65:65 + 2080], second[np.tril_indices(64)], rtol=5e-6, atol=1e-3 * np.sqrt(n))
+        obs = m[65 + 2080:65 + 2080 + 128]
+        assert np.allclose(obs[:64], np.abs(x).sum(axis=0), rtol=5e-6)
+        assert np.allclose(obs[64:], (x * x).sum(axis=0), rtol=5e-6)
+        again = eng.pooled_moments()
+        assert np.array_equal(m, again)             # fixed summation order: bitwise reproducible
