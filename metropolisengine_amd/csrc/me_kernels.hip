@@ -7,7 +7,7 @@
 #include "me_device.h"
 #include "me_dense_mfma.h"
 #include "me_dense_bf16x3.h"
-#include "me_pool_gram64.h"
+#include "me_pool_gram.h"
 #include "me_magphase.h"
 
 // User-energy plugin mode: -DME_USER_SOURCE='"file"' -DME_USER_NAME='"name"' compiles the SAME kernels around a
@@ -356,6 +356,12 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
 #else
 #define ME_SET_NAME nullptr
 #endif
+// dimension-specific first stage of the pooled-moment reduction (float32): a Gram product on the matrix cores
+constexpr auto pool_stage1_f32() -> hipError_t (*)(const void *, long long, double *, int, hipStream_t) {
+  if constexpr (NR == 64 && NC == 0) return launch_pool_gram64;
+  else if constexpr (D + NR + NC <= 32) return launch_pool_gram32<NR, NC>;
+  else return nullptr;
+}
 #if ME_DENSE && !defined(ME_USER_SOURCE)
 hipError_t prepare_matrix_f32(const void *factor_full, void *image, hipStream_t stream) {
   if constexpr (NR == 64 && NC == 0) {
@@ -366,10 +372,9 @@ hipError_t prepare_matrix_f32(const void *factor_full, void *image, hipStream_t 
   return hipSuccess;
 }
 constexpr size_t kMatrixImageBytes = (NR == 64 && NC == 0) ? sizeof(unsigned int) * kBf16FragWords : 0;
-#define ME_PREPARE_MATRIX_F32 kMatrixImageBytes, (kMatrixImageBytes ? prepare_matrix_f32 : nullptr), \
-                              ((NR == 64 && NC == 0) ? launch_pool_gram64 : nullptr)
+#define ME_PREPARE_MATRIX_F32 kMatrixImageBytes, (kMatrixImageBytes ? prepare_matrix_f32 : nullptr), pool_stage1_f32()
 #else
-#define ME_PREPARE_MATRIX_F32 0, nullptr, nullptr
+#define ME_PREPARE_MATRIX_F32 0, nullptr, pool_stage1_f32()
 #endif
 const KernelSet kSetF32 = {ME_SET_NAME, ME_F32, NR, NC, ME_PER_CHAIN != 0, (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0), has_energy, energy_terms, step<float>,
                            (NC > 0 && ME_PER_CHAIN) ? magphase<float> : nullptr, measure<float>, init_energy<float>,

@@ -110,4 +110,85 @@ inline hipError_t launch_pool_gram64(const void *x, long long n, double *partial
   return hipGetLastError();
 }
 
+// The same idea for small parameter spaces: all augmented rows [x (D) | |x_r| (NR) | |z_c| (NC)] fit one 32-row block
+// (D + NR + NC <= 32: every prebuilt kernel set except 64 real parameters), so a tile costs 32 MFMAs; the products the
+// layout does not ask for (anything with an |.| row) are simply not written.  Row sums: lane l sums half of row l & 31.
+template <int NR, int NC>
+__global__ void __launch_bounds__(64 * kGramWaves) k_pool_gram32(const float *__restrict__ x, long long n,
+                                                                 double *__restrict__ partials, int n_rows) {
+  constexpr int D = NR + 2 * NC;
+  constexpr int n_aug = D + NR + NC;
+  static_assert(n_aug <= 32, "one 32-row MFMA block");
+  constexpr int n_entries = 1 + n_aug + D * (D + 1) / 2;
+  __shared__ float slab[kGramWaves][32 * kGramPitch];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row_id = blockIdx.x * kGramWaves + wave;
+  if (row_id >= n_rows) return;
+  float *tile = slab[wave];
+  const int r31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int r = n_aug; r < 32; ++r) tile[r * kGramPitch + lane] = 0.0f;     // unused rows stay zero
+
+  double g[16], row_sum = 0.0, count = 0.0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) g[r] = 0.0;
+
+  const long long n_tiles = (n + 63) / 64;
+  float next[D];
+  auto request = [&](long long t) {
+    const long long c = t * 64 + lane;
+    const bool live = t < n_tiles && c < n;
+    const long long cc = live ? c : 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const float v = x[(long long)d * n + cc];
+      next[d] = live ? v : 0.0f;
+    }
+  };
+  request(row_id);
+  for (long long t = row_id; t < n_tiles; t += n_rows) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) tile[d * kGramPitch + lane] = next[d];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) tile[(D + i) * kGramPitch + lane] = __builtin_fabsf(next[i]);
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+      tile[(D + NR + j) * kGramPitch + lane] =
+          (float)sqrt((double)next[NR + j] * next[NR + j] + (double)next[NR + NC + j] * next[NR + NC + j]);
+    request(t + n_rows);
+    count += (double)(n - t * 64 < 64 ? n - t * 64 : 64);
+    float s = 0.0f;
+#pragma unroll 16
+    for (int col = 0; col < 32; ++col) s += tile[r31 * kGramPitch + 32 * h + col];
+    s += __shfl_xor(s, 32, 64);
+    row_sum += (double)s;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const float a = tile[r31 * kGramPitch + 2 * k + h];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[r] += (double)acc[r];
+  }
+
+  double *out = partials + (long long)row_id * n_entries;
+  if (lane == 0) out[0] = count;
+  if (lane < n_aug) out[1 + lane] = row_sum;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = acc_row(r) + 4 * h, j = r31;
+    if (i < D && j <= i) out[1 + n_aug + i * (i + 1) / 2 + j] = g[r];
+  }
+}
+
+template <int NR, int NC>
+inline hipError_t launch_pool_gram32(const void *x, long long n, double *partials, int n_rows, hipStream_t stream) {
+  hipLaunchKernelGGL((k_pool_gram32<NR, NC>), dim3((unsigned)((n_rows + kGramWaves - 1) / kGramWaves)), dim3(64 * kGramWaves), 0,
+                     stream, (const float *)x, n, partials, n_rows);
+  return hipGetLastError();
+}
+
 }  // namespace me

@@ -97,7 +97,7 @@ def test_fp32_mfma_variant_in_child_process():
 
 
 def test_pooled_moments_gram_kernel_matches_numpy():
-    """64 real parameters pool their second moments with the matrix-core Gram kernel (me_pool_gram64.h); the result must be
+    """64 real parameters pool their second moments with the matrix-core Gram kernel (me_pool_gram.h); the result must be
     the plain sums over the chains' current states (ragged last tile, several tiles per wavefront)."""
     from metropolisengine_amd.distributed import moments_size
     for n in (64 * 3 + 5, (1 << 16) + 64 * 7 + 9):
