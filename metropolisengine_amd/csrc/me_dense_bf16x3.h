@@ -49,8 +49,11 @@ __device__ __forceinline__ bf16x8 as_frag(const unsigned int (&w)[4]) {
 // y = M x for the wave's 64 columns; x is read through `get(k)` (this lane's X[k]) and the result handed out row by
 // row through `emit(row, y[row])` (this lane's chain), so that no second 64-register array is live beside the
 // accumulators; frags = image of M's three bf16 pieces in fragment order (stage_bf16_fragments).
+// frags3: where the THIRD piece's fragments are read from (normally frags itself; the half-size workgroup variant keeps
+// only pieces 1 and 2 in LDS and reads piece 3, used by one product in six, from the global image).
 template <class Get, class Emit>
-__device__ __forceinline__ void wave_matmul_64_bf16x3(const unsigned int *frags, Get &&get, Emit &&emit, int lane) {
+__device__ __forceinline__ void wave_matmul_64_bf16x3(const unsigned int *frags, const unsigned int *frags3, Get &&get,
+                                                      Emit &&emit, int lane) {
   f32x16 acc[2][2];
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb)
@@ -95,7 +98,8 @@ __device__ __forceinline__ void wave_matmul_64_bf16x3(const unsigned int *frags,
     for (int qa = 2; qa >= 0; --qa)
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
-        const u32x4 raw = *reinterpret_cast<const u32x4 *>(frags + ((((qa * 2 + mb) * 4 + s) * 64 + lane) << 2));
+        const unsigned int *src = qa == 2 ? frags3 : frags;
+        const u32x4 raw = *reinterpret_cast<const u32x4 *>(src + ((((qa * 2 + mb) * 4 + s) * 64 + lane) << 2));
         const bf16x8 a = __builtin_bit_cast(bf16x8, raw);
 #pragma unroll
         for (int qx = 2 - qa; qx >= 0; --qx) {
@@ -136,9 +140,14 @@ __device__ __forceinline__ void stage_bf16_fragments(unsigned int *lds_frag, con
 // A's fragments live in LDS (24 KiB + 128 KiB of proposals), copied per block from the image that
 // k_dense64_bf16_fragments prepares once per engine.  CK_SHARED has no LDS left for the factor's fragments: L's are
 // read from its global image (24 KiB, L1/L2-resident).
-template <int CK>
+// THREADS = 512: one workgroup per CU (24 KiB of fragments + 128 KiB of proposals).  THREADS = 256: pieces 1 and 2 of A
+// in LDS (16 KiB) + 64 KiB of proposals = 80 KiB, so that TWO independent workgroups share a CU's 160 KiB and one's
+// memory phases overlap the other's arithmetic; piece 3 is read from the global image.
+template <int THREADS>
+constexpr int dense64_lds_frag_words() { return THREADS == 512 ? kBf16FragWords : (kBf16FragWords / 3) * 2; }
+template <int CK, int THREADS>
 constexpr size_t dense64_bf16_lds_bytes() {
-  return sizeof(float) * (kBf16FragWords + 64 * kDenseBlockThreads);
+  return sizeof(float) * (dense64_lds_frag_words<THREADS>() + 64 * THREADS);
 }
 
 template <int UNUSED = 0>
@@ -149,8 +158,8 @@ __global__ void k_dense64_bf16_fragments(const float *__restrict__ m, unsigned i
   for (int i = threadIdx.x; i < kBf16FragWords; i += blockDim.x) out[i] = frag[i];
 }
 
-template <int CK>
-__global__ void __launch_bounds__(kDenseBlockThreads, 2) k_step_dense64_bf16x3(StepArgs<float> a,
+template <int CK, int THREADS>
+__global__ void __launch_bounds__(THREADS, 2) k_step_dense64_bf16x3(StepArgs<float> a,
                                                                              const unsigned int *__restrict__ afrag,
                                                                              const unsigned int *lfrag) {
   constexpr int D = 64;
@@ -158,16 +167,18 @@ __global__ void __launch_bounds__(kDenseBlockThreads, 2) k_step_dense64_bf16x3(S
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
   extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
   unsigned int *lds_a = smem_u;
-  float *lds_xp = reinterpret_cast<float *>(smem_u + kBf16FragWords) + threadIdx.x;   // this lane's column, stride 512
+  constexpr int FRAG_WORDS = dense64_lds_frag_words<THREADS>();
+  const unsigned int *a_piece3 = THREADS == 512 ? lds_a : afrag;   // see dense64_bf16_lds_bytes
+  float *lds_xp = reinterpret_cast<float *>(smem_u + FRAG_WORDS) + threadIdx.x;   // this lane's column, stride THREADS
 
   const int lane = threadIdx.x & 63;
   unsigned int wave_accepted = 0;
   bool bad_energy = false, bad_width = false;
-  const long long stride = (long long)gridDim.x * kDenseBlockThreads;
+  const long long stride = (long long)gridDim.x * THREADS;
   const Field<float> fx(a.x, a.n, D), fe(a.energy, a.n, 1), fw(a.width, a.n, 1);
 
   // every lane stays active (MFMA and permlane need the whole wavefront): tail lanes shadow the last chain
-  long long base = (long long)blockIdx.x * kDenseBlockThreads + (threadIdx.x & ~63);
+  long long base = (long long)blockIdx.x * THREADS + (threadIdx.x & ~63);
   bool have = base < a.n;
   bool live = false;
   unsigned int coff = 0;
@@ -194,15 +205,16 @@ __global__ void __launch_bounds__(kDenseBlockThreads, 2) k_step_dense64_bf16x3(S
   // A's fragment image (24 KiB, prepared once per engine by k_dense64_bf16_fragments) is requested first and the first
   // tile's state right behind it: the image lands, goes to LDS and the block passes its barrier while the state rows
   // are still arriving
-  static_assert(kBf16FragWords / 4 == 3 * kDenseBlockThreads, "three 16-byte pieces of the image per thread");
-  u32x4 image[3];
+  constexpr int PER_THREAD = FRAG_WORDS / 4 / THREADS;   // 16-byte pieces of the image per thread: 3 (512) or 4 (256)
+  static_assert(PER_THREAD * THREADS * 4 == FRAG_WORDS, "the image divides evenly over the workgroup");
+  u32x4 image[PER_THREAD];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) image[k] = reinterpret_cast<const u32x4 *>(afrag)[k * kDenseBlockThreads + threadIdx.x];
+  for (int k = 0; k < PER_THREAD; ++k) image[k] = reinterpret_cast<const u32x4 *>(afrag)[k * THREADS + threadIdx.x];
   __builtin_amdgcn_sched_barrier(0);
   load_tile();   // unconditional (a wave past the end shadows the last chain): a branch here would make the
                  // s_waitcnt in front of the LDS writes below wait for the tile as well
 #pragma unroll
-  for (int k = 0; k < 3; ++k) reinterpret_cast<u32x4 *>(lds_a)[k * kDenseBlockThreads + threadIdx.x] = image[k];
+  for (int k = 0; k < PER_THREAD; ++k) reinterpret_cast<u32x4 *>(lds_a)[k * THREADS + threadIdx.x] = image[k];
   __syncthreads();
 
   while (have) {
@@ -222,13 +234,13 @@ __global__ void __launch_bounds__(kDenseBlockThreads, 2) k_step_dense64_bf16x3(S
           N_::normal_pair(r.x, r.y, g[0], g[1]);
           N_::normal_pair(r.z, r.w, g[2], g[3]);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) lds_xp[(4 * b + i) * kDenseBlockThreads] = g[i];
+          for (int i = 0; i < 4; ++i) lds_xp[(4 * b + i) * THREADS] = g[i];
         }
         // x' = x + w L g; every lane has read all of g before the first row comes out.  The clobber keeps the
         // (loop-invariant) fragment loads of L inside the sweep: hoisted, they would pin 96 registers.
         asm volatile("" ::: "memory");
-        wave_matmul_64_bf16x3(lfrag, [&](int k) { return lds_xp[k * kDenseBlockThreads]; },
-                              [&](int row, float v) { lds_xp[row * kDenseBlockThreads] = x[row] + w * v; }, lane);
+        wave_matmul_64_bf16x3(lfrag, lfrag, [&](int k) { return lds_xp[k * THREADS]; },
+                              [&](int row, float v) { lds_xp[row * THREADS] = x[row] + w * v; }, lane);
       } else {
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
@@ -238,12 +250,12 @@ __global__ void __launch_bounds__(kDenseBlockThreads, 2) k_step_dense64_bf16x3(S
           N_::normal_pair(r.x, r.y, g[0], g[1]);
           N_::normal_pair(r.z, r.w, g[2], g[3]);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) lds_xp[(4 * b + i) * kDenseBlockThreads] = x[4 * b + i] + w * g[i];
+          for (int i = 0; i < 4; ++i) lds_xp[(4 * b + i) * THREADS] = x[4 * b + i] + w * g[i];
         }
       }
       float e_new = 0.0f;                                   // E = x'^T (A x')
-      wave_matmul_64_bf16x3(lds_a, [&](int k) { return lds_xp[k * kDenseBlockThreads]; },
-                            [&](int row, float v) { e_new += lds_xp[row * kDenseBlockThreads] * v; }, lane);
+      wave_matmul_64_bf16x3(lds_a, a_piece3, [&](int k) { return lds_xp[k * THREADS]; },
+                            [&](int row, float v) { e_new += lds_xp[row * THREADS] * v; }, lane);
       ctr.w = step_hi | 16u;                                // word 64 = block 16, output 0
       const float u = N_::unit(philox4x32_10(ctr, a.seed_lo, a.seed_hi).x);
       bool rejected = false;
@@ -255,7 +267,7 @@ __global__ void __launch_bounds__(kDenseBlockThreads, 2) k_step_dense64_bf16x3(S
       bad_energy |= (live && !rejected && !N_::finite(e_new));
       if (accept) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) x[d] = lds_xp[d * kDenseBlockThreads];
+        for (int d = 0; d < D; ++d) x[d] = lds_xp[d * THREADS];
       }
       e = accept ? e_new : e;
       w = N_::adapt(w, accept, a.ratio, a.p, a.damping, a.up, a.down);
@@ -273,7 +285,7 @@ __global__ void __launch_bounds__(kDenseBlockThreads, 2) k_step_dense64_bf16x3(S
     if (have) load_tile();
   }
   if (lane == 0 && wave_accepted) {
-    unsigned long long *slot = a.accept_slots + (size_t)blockIdx.x * (kDenseBlockThreads / 64) + (threadIdx.x >> 6);
+    unsigned long long *slot = a.accept_slots + (size_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
     *slot += (unsigned long long)wave_accepted;
   }
   const unsigned int bits = (bad_energy ? ST_NONFINITE_ENERGY : 0u) | (bad_width ? ST_BAD_WIDTH : 0u);
@@ -290,29 +302,44 @@ inline bool dense64_exact_fp32_mfma() {
 }
 
 // Host launcher.  afrag / lfrag (CK_SHARED): fragment images of A / the factor made by k_dense64_bf16_fragments.
+template <int CK, int THREADS>
+inline hipError_t launch_step_dense64_bf16x3_threads(const StepArgs<float> &a, const unsigned int *afrag,
+                                                     const unsigned int *lfrag, int grid_blocks, hipStream_t stream) {
+  static const hipError_t attr = hipFuncSetAttribute((const void *)k_step_dense64_bf16x3<CK, THREADS>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)dense64_bf16_lds_bytes<CK, THREADS>());
+  if (attr != hipSuccess) return attr;
+  // Persistent workgroups, four wavefront-slots' worth per SIMD pair (two 512-thread or four 256-thread groups per CU),
+  // each striding over its tiles with the next tile's loads issued before the current one retires: beats one group per
+  // tile by 12 % at one sweep per launch (start-up: image copy + barrier with nothing else resident) and ties when
+  // sweeps are fused.  tools/dev/time_dense64_grid.py
+  static const int cus = [] {
+    int device = 0, count = 0;
+    if (hipGetDevice(&device) != hipSuccess ||
+        hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || count <= 0)
+      return 256;
+    return count;
+  }();
+  long long blocks = (a.n + THREADS - 1) / THREADS;
+  const long long cap = grid_blocks > 0 ? grid_blocks : (long long)cus * (1024 / THREADS);
+  if (blocks > cap) blocks = cap;
+  constexpr size_t lds = dense64_bf16_lds_bytes<CK, THREADS>();
+  hipLaunchKernelGGL((k_step_dense64_bf16x3<CK, THREADS>), dim3((unsigned)blocks), dim3(THREADS), lds, stream, a, afrag,
+                     lfrag);
+  return hipGetLastError();
+}
+
+// Default: the half-size workgroups, two per CU (63 -> 60 us per sweep at one sweep per launch, 36.4 -> 35.1 fused, 2^19
+// chains); METROPOLIS_DENSE64_THREADS=512 selects one 512-thread workgroup per CU.
 template <int CK>
 inline hipError_t launch_step_dense64_bf16x3(const StepArgs<float> &a, const unsigned int *afrag, const unsigned int *lfrag,
                                              int grid_blocks, hipStream_t stream) {
-  static const hipError_t attr = hipFuncSetAttribute((const void *)k_step_dense64_bf16x3<CK>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)dense64_bf16_lds_bytes<CK>());
-  if (attr != hipSuccess) return attr;
-  // LDS admits one block per CU; two persistent blocks per CU (each striding over its tiles, the next tile's loads
-  // issued before the current one retires) beat one block per tile by 12 % at one sweep per launch (block start-up:
-  // image copy + barrier with nothing else resident) and tie when sweeps are fused.  tools/dev/time_dense64_grid.py
-  static const int two_per_cu = [] {
-    int device = 0, cus = 0;
-    if (hipGetDevice(&device) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0)
-      return 512;
-    return 2 * cus;
+  static const bool full = [] {
+    const char *v = std::getenv("METROPOLIS_DENSE64_THREADS");
+    return v && std::atoi(v) == 512;
   }();
-  long long blocks = (a.n + kDenseBlockThreads - 1) / kDenseBlockThreads;
-  const long long cap = grid_blocks > 0 ? grid_blocks : two_per_cu;
-  if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(k_step_dense64_bf16x3<CK>, dim3((unsigned)blocks), dim3(kDenseBlockThreads),
-                     dense64_bf16_lds_bytes<CK>(), stream, a, afrag, lfrag);
-  return hipGetLastError();
+  if (full) return launch_step_dense64_bf16x3_threads<CK, 512>(a, afrag, lfrag, grid_blocks, stream);
+  return launch_step_dense64_bf16x3_threads<CK, 256>(a, afrag, lfrag, grid_blocks, stream);
 }
 
 }  // namespace me

@@ -21,7 +21,7 @@ __global__ void k_test(const unsigned int *frag_src, const float *m, const float
   if (threadIdx.x >= 64) return;
   float v[64], out[64];
   for (int d = 0; d < 64; ++d) v[d] = x[d * 64 + lane];
-  wave_matmul_64_bf16x3(frag, [&](int k) { return v[k]; }, [&](int row, float val) { out[row] = val; }, lane);
+  wave_matmul_64_bf16x3(frag, frag, [&](int k) { return v[k]; }, [&](int row, float val) { out[row] = val; }, lane);
   for (int d = 0; d < 64; ++d) y[d * 64 + lane] = out[d];
   wave_matmul_64(frag32, [&](int b, int t, float (&q)[4]) { if (t < 4) q[t] = v[4 * b + t]; }, out, lane, false);
   for (int d = 0; d < 64; ++d) y32[d * 64 + lane] = out[d];
