@@ -162,16 +162,18 @@ __global__ void __launch_bounds__(64 * kGramWaves) k_pool_gram32(const float *__
     for (int col = 0; col < 32; ++col) s += tile[r31 * kGramPitch + 32 * h + col];
     s += __shfl_xor(s, 32, 64);
     row_sum += (double)s;
-    f32x16 acc;
+    f32x16 acc[2];     // two accumulators: consecutive MFMAs do not wait on each other
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.0f;
 #pragma unroll 8
-    for (int k = 0; k < 32; ++k) {
-      const float a = tile[r31 * kGramPitch + 2 * k + h];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, acc, 0, 0, 0);
+    for (int k = 0; k < 32; k += 2) {
+      const float a0 = tile[r31 * kGramPitch + 2 * k + h];
+      const float a1 = tile[r31 * kGramPitch + 2 * k + 2 + h];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, a0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a1, acc[1], 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) g[r] += (double)acc[r];
+    for (int r = 0; r < 16; ++r) g[r] += (double)(acc[0][r] + acc[1][r]);
   }
 
   double *out = partials + (long long)row_id * n_entries;
