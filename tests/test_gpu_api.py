@@ -128,3 +128,22 @@ def test_set_reject_condition_after_construction():
         setter.set_reject_condition(lambda r, c: False)
     with pytest.raises(ValueError):
         me.MetropolisEngine(me.IsoQuadratic(1.0), me.AbsReal0AtLeast(1.0), None, [0j], temp=1.0, n_chains=8)
+
+
+def test_largest_register_resident_dimension():
+    """96 real degrees of freedom is the largest compile-on-demand kernel set (build.MAX_REGISTER_DOF); beyond it the
+    engine refuses.  The sampler must still be right there: stationary variance T / (2 a) per coordinate."""
+    n, a = 1 << 12, 2.0
+    eng = me.MetropolisEngine(me.IsoQuadratic(a), initial_real_params=[0.0] * 96, temp=1.0, n_chains=n, seed=31,
+                              sampling_width=0.08, cov_mode="fixed")
+    eng.step_all(1500)
+    x = eng._get(0)
+    assert x.shape == (n, 96)
+    var = x.var(axis=0)
+    assert np.all(np.abs(var - 0.25) < 6 * 0.25 * np.sqrt(2.0 / n))
+    assert np.all(np.abs(x.mean(axis=0)) < 6 * np.sqrt(0.25 / n))
+    assert 0.15 < eng.acceptance_rate() < 0.5
+    eng.measure()
+    assert np.allclose(eng.real_mean[0], (x[0] + 0.0) / 2, atol=1e-6)      # mean of the initial point and the state
+    with pytest.raises(RuntimeError):
+        me.MetropolisEngine(me.IsoQuadratic(a), initial_real_params=[0.0] * 97, temp=1.0, n_chains=64)
