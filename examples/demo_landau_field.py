@@ -3,7 +3,7 @@ E = k (1-x)^2 + k (1-y)^2 + x y (alpha |c|^2 + beta |c|^4), passed as the energy
 {"complex": {"field"}, "real": {"field", "area"}, "all": {"field", "area"}}, temp 0.1, 100 x (10 steps + 1 measure),
 then the time series as a DataFrame -- on the GPU engine.
 
-    python examples/toymodel_complex_and_real.py           (needs an MI355X and the built library)
+    python examples/demo_landau_field.py           (needs an MI355X and the built library)
 """
 import os
 import sys
@@ -23,9 +23,10 @@ def main(k=1.0, alpha=-1.0, beta=0.5, temp=0.1, n_measures=100, steps_per_measur
         for _ in range(steps_per_measure):
             engine.step_all()
         engine.measure()     # running means, covariance estimate, observables; one row of the time series
-    print("mean", engine.real_mean, engine.complex_mean)
-    print("cov", engine.covariance_matrix_real, engine.covariance_matrix_complex)
-    print(list(zip(engine.observables_names, engine.observables)))
+    print("plane size <x>, <y> = %s   field <c> = %s" % (engine.real_mean, engine.complex_mean))
+    print("covariance of (x, y):\n%s\nvariance of c: %s" % (engine.covariance_matrix_real, engine.covariance_matrix_complex))
+    for name, value in zip(engine.observables_names, engine.observables_mean):
+        print("   <%s> = %.4f" % (name, value))
     print("energy terms", engine.energy)
     engine.save_time_series()          # prints the DataFrame, as the reference does
     return engine

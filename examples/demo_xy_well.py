@@ -2,7 +2,7 @@
 temp 0.1, 1000 x (10 steps + 1 measure)) on the GPU engine -- once as the reference runs it (one chain) and once as an
 ensemble of 2^16 chains whose pooled statistics replace the single chain's time averages.
 
-    python examples/toymodel_xypotentialwell.py            (needs an MI355X and the built library)
+    python examples/demo_xy_well.py            (needs an MI355X and the built library)
 """
 import os
 import sys
@@ -24,9 +24,9 @@ def main(const=1.0, temp=0.1, n_measures=1000, steps_per_measure=10, ensemble=1 
         for _ in range(steps_per_measure):
             engine.step_all()
         engine.measure()
-    print("one chain   mean", engine.real_mean, engine.complex_mean)
-    print("one chain   cov ", engine.covariance_matrix_real)
-    print(list(zip(engine.observables_names, engine.observables)))
+    print("single chain: running mean %s, running covariance\n%s" % (engine.real_mean, engine.covariance_matrix_real))
+    for name, value in zip(engine.observables_names, engine.observables_mean):
+        print("   <%s> = %.4f" % (name, value))
 
     # --- the same protocol on an ensemble: one launch steps every chain, step_all(10) fuses the ten sweeps
     many = me.MetropolisEngine(energy, initial_real_params=[0.0, 0.0], temp=temp, n_chains=ensemble, seed=seed)

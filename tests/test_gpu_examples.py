@@ -17,7 +17,7 @@ def _load(name):
 
 
 def test_xy_potential_well_demo(capsys):
-    single, many, stats = _load("toymodel_xypotentialwell").main(n_measures=120, ensemble=1 << 14)
+    single, many, stats = _load("demo_xy_well").main(n_measures=120, ensemble=1 << 14)
     assert single.measure_step_counter == 121 and single.covariance_matrix_real.shape == (2, 2)
     # stationary variance of exp(-c (x^2 + y^2) / T) is T / (2 c) = 0.05 per coordinate
     assert np.all(np.abs(np.diag(stats["covariance"]) - 0.05) < 6 * 0.05 * np.sqrt(2.0 / (1 << 14)))
@@ -27,7 +27,7 @@ def test_xy_potential_well_demo(capsys):
 
 
 def test_complex_and_real_demo(capsys):
-    eng = _load("toymodel_complex_and_real").main(n_measures=60)
+    eng = _load("demo_landau_field").main(n_measures=60)
     assert set(eng.energy) == {"field", "area"}
     assert list(eng.df.columns) == ["abs_param_0", "abs_param_1", "abs_param_2", "param_0_squared", "param_1_squared",
                                     "area_energy", "field_energy", "param_0", "param_1", "real_group_sampling_width",
