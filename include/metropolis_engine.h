@@ -212,6 +212,16 @@ int me_last_error(me_engine *engine, char *buf, size_t buf_bytes);
 /* Capability query: 1 if a kernel set for this combination is compiled in. */
 int me_supported(int32_t dtype, int32_t n_real, int32_t n_complex, int32_t energy_kind);
 
+/* Equilibration detection for a batch of recorded series (host arrays in, host arrays out; engine-independent):
+ * for each of the n_series rows of series[n_series][length] the production start t0 that maximises the number of
+ * effectively uncorrelated samples (length - t0 + 1) / g(t0), with g the statistical inefficiency of the tail.
+ * Replaces the per-column pymbar.timeseries.detectEquilibration calls of statistics.py:25-48 /
+ * metropolis_engine.py:481-504 (PARITY UNPINNED: pymbar is absent; this follows the published algorithm exactly as
+ * metropolisengine_amd/statistics.py restates it).  fast != 0: lag increments grow by one (pymbar's fast=True);
+ * nskip: stride of the candidate starts.  Constant series report (0, 1, 1). */
+int me_detect_equilibration(int32_t device_id, const double *series, int64_t n_series, int64_t length, int32_t fast,
+                            int32_t nskip, int64_t *t0, double *g, double *neff_max);
+
 #ifdef __cplusplus
 }
 #endif

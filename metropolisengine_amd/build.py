@@ -92,7 +92,7 @@ def build(force=False, jobs=None, verbose=True):
     for nr, nc, dense, per_chain in KERNEL_DIMS:
         units.append((os.path.join(OBJ_DIR, "me_kernels_%d_%d.o" % (nr, nc)), os.path.join(CSRC, "me_kernels.hip"),
                       ["-DME_NR=%d" % nr, "-DME_NC=%d" % nc, "-DME_DENSE=%d" % dense, "-DME_PER_CHAIN=%d" % per_chain]))
-    for name in ("me_generic", "me_api"):
+    for name in ("me_generic", "me_statistics", "me_api"):
         units.append((os.path.join(OBJ_DIR, name + ".o"), os.path.join(CSRC, name + ".hip"), []))
 
     todo = []

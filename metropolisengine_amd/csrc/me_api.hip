@@ -934,6 +934,51 @@ int me_time_steps(me_engine *e, int32_t n_launches, int32_t n_sweeps, float *ela
   return ME_OK;
 }
 
+int me_detect_equilibration(int32_t device_id, const double *series, int64_t n_series, int64_t length, int32_t fast,
+                            int32_t nskip, int64_t *t0, double *g, double *neff_max) {
+  if (!series || !t0 || !g || !neff_max) return fail(nullptr, ME_ERR_INVALID, "null pointer");
+  if (n_series <= 0 || length < 3 || nskip < 1) return fail(nullptr, ME_ERR_INVALID, "need n_series > 0, length >= 3, nskip >= 1");
+  ME_HIP(nullptr, hipSetDevice(device_id));
+  const size_t m = (size_t)(length - 1), ns = (size_t)n_series;
+  double *d_series = nullptr, *d_scratch = nullptr, *d_g = nullptr, *d_neff = nullptr;
+  long long *d_t0 = nullptr;
+  hipStream_t stream = nullptr;
+  auto cleanup = [&]() {
+    for (void *p : {(void *)d_series, (void *)d_scratch, (void *)d_g, (void *)d_neff, (void *)d_t0})
+      if (p) (void)hipFree(p);
+  };
+#define ME_EQ_HIP(call)                                                                    \
+  do {                                                                                     \
+    hipError_t err__ = (call);                                                             \
+    if (err__ != hipSuccess) {                                                             \
+      cleanup();                                                                           \
+      return fail(nullptr, ME_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(err__)); \
+    }                                                                                      \
+  } while (0)
+  ME_EQ_HIP(hipMalloc((void **)&d_series, sizeof(double) * ns * (size_t)length));
+  ME_EQ_HIP(hipMalloc((void **)&d_scratch, sizeof(double) * 2 * ns * m));
+  ME_EQ_HIP(hipMalloc((void **)&d_g, sizeof(double) * ns));
+  ME_EQ_HIP(hipMalloc((void **)&d_neff, sizeof(double) * ns));
+  ME_EQ_HIP(hipMalloc((void **)&d_t0, sizeof(long long) * ns));
+  ME_EQ_HIP(hipMemcpy(d_series, series, sizeof(double) * ns * (size_t)length, hipMemcpyHostToDevice));
+  ME_EQ_HIP(launch_detect_equilibration(d_series, n_series, length, fast, nskip, d_scratch, d_t0, d_g, d_neff, stream));
+  ME_EQ_HIP(hipDeviceSynchronize());
+  static_assert(sizeof(long long) == sizeof(int64_t), "t0 is copied out as int64");
+  ME_EQ_HIP(hipMemcpy(t0, d_t0, sizeof(int64_t) * ns, hipMemcpyDeviceToHost));
+  ME_EQ_HIP(hipMemcpy(g, d_g, sizeof(double) * ns, hipMemcpyDeviceToHost));
+  ME_EQ_HIP(hipMemcpy(neff_max, d_neff, sizeof(double) * ns, hipMemcpyDeviceToHost));
+#undef ME_EQ_HIP
+  cleanup();
+  // a constant series has no autocorrelation: the host convention is (0, 1, 1)
+  for (size_t s = 0; s < ns; ++s) {
+    const double *row = series + s * (size_t)length;
+    bool constant = true;
+    for (int64_t i = 1; i < length && constant; ++i) constant = row[i] == row[0];
+    if (constant) { t0[s] = 0; g[s] = 1.0; neff_max[s] = 1.0; }
+  }
+  return ME_OK;
+}
+
 int me_last_error(me_engine *e, char *buf, size_t buf_bytes) {
   if (!buf || buf_bytes == 0) return ME_ERR_INVALID;
   const std::string &s = e ? e->err : g_create_error;

@@ -122,6 +122,10 @@ int pool_reduce_blocks(long long n, int n_real, int n_complex);
 hipError_t launch_trace(const void *x, const void *energy, const void *width, long long n, int d, int n_terms,
                         int width_rows, int dtype, long long n_traced, long long stride, double *out, hipStream_t stream);
 // total[0] = sum of slots[0 .. n_slots)
+// Batched equilibration detection (me_statistics.hip; me_detect_equilibration in the public header).
+hipError_t launch_detect_equilibration(const double *series, long long n_series, long long length, int fast, int nskip,
+                                       double *scratch, long long *t0_out, double *g_out, double *neff_out,
+                                       hipStream_t stream);
 hipError_t launch_sum_slots(const unsigned long long *slots, long long n_slots, unsigned long long *total,
                             hipStream_t stream);
 

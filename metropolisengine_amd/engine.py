@@ -125,7 +125,7 @@ class MetropolisEngine:
         init = np.ascontiguousarray(np.concatenate((real0, cplx0.real, cplx0.imag)), dtype=np.float64)
         cfg = _capi.MeConfig()
         cfg.abi_version = _capi.ABI_VERSION
-        cfg.device_id = int(device)
+        cfg.device_id = self.device = int(device)
         cfg.n_chains = self.n_chains
         cfg.chain_offset = self.chain_offset
         cfg.seed = self.seed
@@ -533,6 +533,26 @@ class MetropolisEngine:
     def save_time_series(self):
         self.df = self.time_series_frame(0)
         print(self.df)                                                                   # :479
+
+    def equilibration_points(self, fast=True, nskip=1):
+        """Equilibration start, statistical inefficiency and effective sample count of EVERY traced chain and recorded
+        column in one GPU batch (``me_detect_equilibration``): ``{column: (t0[k], g[k], Neff[k])}`` over the ``k`` traced
+        chains.  The many-chain form of ``get_equilibration_points`` (statistics.py:25-48); PARITY UNPINNED like it."""
+        from . import statistics
+        names, rows = [], []
+        for chain in range(self.trace_chains):
+            frame = self.time_series_frame(chain)
+            if chain == 0:
+                for name in frame.columns.values:
+                    values = frame[name].to_numpy()
+                    names += [name + "_real", name + "_imag"] if np.iscomplexobj(values) else [name]
+            for name in frame.columns.values:
+                values = frame[name].to_numpy()
+                rows += [values.real, values.imag] if np.iscomplexobj(values) else [values.astype(np.float64)]
+        t0, g, neff = statistics.detect_equilibration_batch(np.stack(rows), fast=fast, nskip=nskip, device=self.device)
+        k, c = self.trace_chains, len(names)
+        t0, g, neff = t0.reshape(k, c), g.reshape(k, c), neff.reshape(k, c)
+        return {name: (t0[:, i], g[:, i], neff[:, i]) for i, name in enumerate(names)}
 
     def save_equilibrium_stats(self, external_df=None):
         """metropolis_engine.py:481-504: equilibration point per recorded column, the global cut-off (largest ``t0``

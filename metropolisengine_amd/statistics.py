@@ -56,21 +56,45 @@ def detect_equilibration(series, fast=True, nskip=1):
     return t0, float(g_t[t0]), float(neff_t[t0])
 
 
-def get_equilibration_points(df):
+def detect_equilibration_batch(series, fast=True, nskip=1, device=0):
+    """``detect_equilibration`` for every row of ``series[n_series, T]`` in one call on the GPU
+    (``me_detect_equilibration``: one wavefront per (series, start)); returns ``(t0, g, Neff_max)`` arrays.  An
+    ensemble run records thousands of chains x columns, each an O(T^2) scan on the host."""
+    import ctypes
+    from . import _capi
+    a = np.ascontiguousarray(series, dtype=np.float64)
+    if a.ndim != 2:
+        raise ValueError("series must be [n_series, length]")
+    n, length = a.shape
+    t0 = np.zeros(n, dtype=np.int64)
+    g = np.ones(n)
+    neff = np.ones(n)
+    dp = ctypes.POINTER(ctypes.c_double)
+    _capi.check(_capi.load().me_detect_equilibration(
+        int(device), a.ctypes.data_as(dp), n, length, int(bool(fast)), int(nskip),
+        t0.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), g.ctypes.data_as(dp), neff.ctypes.data_as(dp)))
+    return t0, g, neff
+
+
+def get_equilibration_points(df, device=None):
     """Per column ``[t0, g, Neff_max]``; constant columns are skipped and complex columns split into ``_real`` /
-    ``_imag`` (statistics.py:25-48)."""
-    out = {}
+    ``_imag`` (statistics.py:25-48).  With ``device`` set, all columns go to the GPU in one batch."""
+    names, rows = [], []
     for name in df.columns.values:
         column = df.loc[:, name]
         if column.nunique() <= 1:
             continue
         values = column.to_numpy()
         if np.iscomplexobj(values):
-            out[name + "_real"] = list(detect_equilibration(values.real))
-            out[name + "_imag"] = list(detect_equilibration(values.imag))
+            names += [name + "_real", name + "_imag"]
+            rows += [values.real, values.imag]
         else:
-            out[name] = list(detect_equilibration(values))
-    return out
+            names.append(name)
+            rows.append(values.astype(np.float64))
+    if device is not None and rows:
+        t0, g, neff = detect_equilibration_batch(np.stack(rows), device=device)
+        return {name: [int(t0[i]), float(g[i]), float(neff[i])] for i, name in enumerate(names)}
+    return {name: list(detect_equilibration(row)) for name, row in zip(names, rows)}
 
 
 def get_equilibrated_means(df, cutoff=None):
