@@ -97,6 +97,27 @@ def get_equilibration_points(df, device=None):
     return {name: list(detect_equilibration(row)) for name, row in zip(names, rows)}
 
 
+def timeseries_from_csv(file_name, column_name=None):
+    """Read a time-series file the reference writes (``df.to_csv``; layout of exampledata.csv: an index column, then
+    observables, ``<term>_energy``, parameters and widths, complex values as ``(re+imj)`` strings) into
+    ``{name: float array}``.  Like ``plottable_timeseries_from_csv`` (statistics.py:6-23) a non-float column becomes
+    ``<name>_real`` plus, when its first entry has a non-zero imaginary part, ``<name>_imag``."""
+    import pandas
+    data = pandas.read_csv(file_name, index_col=0)
+    names = data.columns if column_name is None else [column_name]
+    out = {}
+    for name in names:
+        column = data[name]
+        if column.dtype.kind == "f":
+            out[name] = column.to_numpy(dtype=np.float64)
+            continue
+        values = np.array([complex(str(v).replace(" ", "")) for v in column], dtype=np.complex128)
+        if values[0].imag != 0:
+            out[name + "_imag"] = values.imag.copy()
+        out[name + "_real"] = values.real.copy()
+    return out
+
+
 def get_equilibrated_means(df, cutoff=None):
     """Column means from row ``cutoff`` on (statistics.py:53-64; the reference's ``cutoff=None`` branch calls an
     undefined name, here it takes the largest ``t0``).  Returns ``(means, errors)``; like the reference, ``errors``

@@ -64,3 +64,14 @@ def test_engine_equilibration_points_over_traced_chains():
     want = statistics.detect_equilibration(frame["param_0"].to_numpy())
     assert t0[3] == want[0] and abs(g[3] - want[1]) < 1e-8 * want[1]
     assert np.median(t0) > 0            # the chains start far from equilibrium: a transient is detected
+
+
+def test_batch_on_the_reference_data_file(golden_dir):
+    """Every column of the reference's own recorded run (tests/golden/reference_exampledata300_head.csv)."""
+    import os
+    series = statistics.timeseries_from_csv(os.path.join(golden_dir, "reference_exampledata300_head.csv"))
+    names = [k for k, v in series.items() if np.ptp(v) > 0]
+    t0, g, neff = statistics.detect_equilibration_batch(np.stack([series[k] for k in names]))
+    for i, name in enumerate(names):
+        want = statistics.detect_equilibration(series[name])
+        assert t0[i] == want[0] and abs(g[i] - want[1]) < 1e-8 * want[1], name
