@@ -41,3 +41,21 @@ def test_equilibration_statistics_run_on_reference_data():
         assert 0 <= t0 < 119 and g >= 1.0 and 1.0 <= neff <= 121.0
     # the adaptive width is strongly autocorrelated, the parameter less so
     assert statistics.statistical_inefficiency(series["real_group_sampling_width"]) > 2.0
+
+
+def test_frame_written_by_pandas_round_trips(tmp_path):
+    """engine.df.to_csv(...) -> timeseries_from_csv: the complex parameter columns come back as _real / _imag."""
+    import pandas
+    rng = np.random.default_rng(2)
+    frame = pandas.DataFrame({"abs_param_0": rng.random(30), "total_energy": rng.random(30),
+                              "param_0": rng.random(30), "real_group_sampling_width": rng.random(30),
+                              "param_1": rng.random(30) + 1j * rng.random(30),
+                              "complex_group_sampling_width": rng.random(30)})
+    path = tmp_path / "series.csv"
+    frame.to_csv(path)
+    back = statistics.timeseries_from_csv(str(path))
+    assert set(back) == {"abs_param_0", "total_energy", "param_0", "real_group_sampling_width", "param_1_real",
+                         "param_1_imag", "complex_group_sampling_width"}
+    assert np.allclose(back["param_1_real"], frame["param_1"].to_numpy().real, rtol=1e-15)
+    assert np.allclose(back["param_1_imag"], frame["param_1"].to_numpy().imag, rtol=1e-15)
+    assert np.allclose(back["total_energy"], frame["total_energy"], rtol=1e-15)
