@@ -83,8 +83,10 @@ struct Num<double> {
     const double u1 = unit(wa), u2 = unit(wb);
     const double r = sqrt(-2.0 * log(u1));
     const double theta = 6.283185307179586 * u2;
-    g0 = r * cos(theta);
-    g1 = r * sin(theta);
+    double sn, cs;
+    sincos(theta, &sn, &cs);      // one argument reduction for both (same values as sin() and cos())
+    g0 = r * cs;
+    g1 = r * sn;
   }
   static __device__ __forceinline__ bool uphill(double u, double d, double temp, double) {
     return u <= exp(-d / temp);
