@@ -16,7 +16,7 @@ def load(build=True):
     if not os.path.exists(_LIB):
         if not build:
             raise OSError("oracle/c/libme_oracle.so missing: run `make -C oracle/c`")
-        subprocess.run(["make", "-C", _DIR, "-s"], check=True)
+        subprocess.run(["make", "-C", _DIR, "-s", "libme_oracle.so"], check=True)
     lib = ctypes.CDLL(_LIB)
     lib.meo_create.restype = ctypes.c_void_p
     lib.meo_create.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64,

@@ -1,5 +1,6 @@
 """Pins oracle/philox.py: Random123 known-answer vectors for philox4x32-10 and stream-shape properties."""
 import numpy as np
+import pytest
 
 from oracle import philox
 
@@ -46,3 +47,31 @@ def test_draw_shapes_and_moments():
     # streams of different steps / chains are distinct
     g2, _ = philox.step_draws(seed=99, chain_ids=chains, step=8, n_normals=5)
     assert not np.allclose(g, g2)
+
+
+def test_stream_contract_equals_rocrand_philox_engine():
+    """The vendor generator named by BASELINE.json ("hiprand Philox"): rocRAND's philox4x32_10_engine, evaluated on the
+    host through oracle/c/librocrand_check.so, yields exactly the build's block for
+    (seed, subsequence = step_lo | word3 << 32, offset = 4 * chain) -- see oracle/c/rocrand_check.cpp."""
+    import ctypes
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "c")
+    lib_path = os.path.join(here, "librocrand_check.so")
+    if not os.path.exists(lib_path):
+        done = subprocess.run(["make", "-C", here, "-s", "librocrand_check.so"], capture_output=True, text=True)
+        if done.returncode != 0:
+            pytest.skip("rocRAND headers / hipcc not available: " + done.stderr[-200:])
+    lib = ctypes.CDLL(lib_path)
+    lib.me_rocrand_philox_block.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,
+                                            ctypes.POINTER(ctypes.c_uint32)]
+    out = (ctypes.c_uint32 * 4)()
+    rng = np.random.default_rng(11)
+    cases = [(2026, 0, 0, 0), (2026, (1 << 20) - 1, 999, 4), (0xDEADBEEFCAFEF00D, (1 << 40) + 12345, (1 << 33) + 9, 16),
+             (1, 2 ** 62 - 1, 2 ** 47 + 5, 255)]
+    cases += [(int(rng.integers(0, 2 ** 63)), int(rng.integers(0, 2 ** 62)), int(rng.integers(0, 2 ** 48)),
+               int(rng.integers(0, 2 ** 16))) for _ in range(200)]
+    for seed, chain, step, block in cases:
+        lib.me_rocrand_philox_block(seed, chain, step, block, out)
+        want = philox.step_block(seed, [chain], step, block)
+        assert list(out) == [int(w[0]) for w in want], (seed, chain, step, block)
