@@ -163,11 +163,19 @@ def main():
     import metropolisengine_amd as me
     from metropolisengine_amd.distributed import pooled_statistics
 
+    # Rehearsal on a one-GPU box (never used by the driver): METROPOLIS_BENCH_REHEARSAL=1 puts every rank on GPU 0 and
+    # uses gloo for the barrier / timing reduction / pooled moments, so the multi-rank code path can be exercised there.
+    rehearsal = os.environ.get("METROPOLIS_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     distributed = "RANK" in os.environ           # launched by torch.distributed.run (also at --gpus 1)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     n_local = 1 << args.chains_log2
     engine = me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * N_REAL, None, sampling_width=0.05,
@@ -187,7 +195,7 @@ def main():
         fence()
         wall = time.perf_counter() - t0
         if distributed:
-            t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
+            t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall, dev_ms = float(t[0]), float(t[1])
         return wall, dev_ms
