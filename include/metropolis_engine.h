@@ -188,6 +188,12 @@ int me_accept_stats(me_engine *engine, uint64_t *accepted, uint64_t *proposed);
 int me_pooled_moments_size(me_engine *engine, int64_t *n_doubles);
 int me_pooled_moments(me_engine *engine, double *host_out, int64_t n_doubles);
 int me_pooled_moments_device(me_engine *engine, void *device_out, int64_t n_doubles);
+/* Split form that does not stall the engine's stream: _begin enqueues the reduction behind the work already queued and
+ * the copy to the host on a second stream, and returns at once; steps and measures enqueued afterwards run while the
+ * result travels.  _end waits for that copy only and hands out the moments of the state at the time of _begin.  One
+ * reduction may be in flight per engine (ME_ERR_STATE otherwise). */
+int me_pooled_moments_begin(me_engine *engine);
+int me_pooled_moments_end(me_engine *engine, double *host_out, int64_t n_doubles);
 /* Install the shared proposal factor of ME_COV_POOLED: packed like ME_FIELD_FACTOR, [P] doubles. */
 int me_set_shared_factor(me_engine *engine, const double *packed_factor, int64_t n_doubles);
 

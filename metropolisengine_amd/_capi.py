@@ -51,6 +51,8 @@ SYMBOLS = {
     "me_step_injected": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32, _dp, _dp]),
     "me_field_components": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
     "me_energy_terms": (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
+    "me_pooled_moments_begin": (ctypes.c_int, [_H]),
+    "me_pooled_moments_end": (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_double), ctypes.c_int64]),
     "me_detect_equilibration": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(ctypes.c_double), ctypes.c_int64,
                                                ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                                ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double),

@@ -140,6 +140,10 @@ struct me_engine {
   unsigned int *status = nullptr;
   double *pool_dev = nullptr, *pool_partials = nullptr, *pool_host = nullptr;   // pool_host: pinned
   unsigned long long *host_scratch = nullptr;   // pinned: [0] status bits, [1] accepted total
+  // split pooled-moment reduction (me_pooled_moments_begin/_end): second stream for the copy, two events
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t pool_reduced = nullptr, pool_copied = nullptr;
+  bool pool_pending = false;
   // time-series trace of a few chains (the reference's per-measure appends, :350-356)
   double *trace_dev = nullptr;
   long long trace_chains = 0, trace_stride = 1, trace_rows = 0, trace_capacity = 0;
@@ -276,6 +280,9 @@ void release(me_engine *e) {
                   e->coef_dev, e->row_dev, e->accept_slots, e->accept_total, e->status, e->pool_dev, e->pool_partials, e->trace_dev};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
+  if (e->pool_copied) (void)hipEventDestroy(e->pool_copied);
+  if (e->pool_reduced) (void)hipEventDestroy(e->pool_reduced);
+  if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   if (e->pool_host) (void)hipHostFree(e->pool_host);
   if (e->host_scratch) (void)hipHostFree(e->host_scratch);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -847,6 +854,7 @@ namespace {
 // k_pool_reduce + k_pool_finish into `device_out`, enqueued on the engine's stream (no synchronisation)
 int enqueue_pooled_moments(me_engine *e, void *device_out, int64_t n_doubles) {
   if (n_doubles != moments_size(e->nr, e->nc)) return fail(e, ME_ERR_INVALID, "wrong pooled-moment buffer length");
+  if (e->pool_pending) return fail(e, ME_ERR_STATE, "a pooled-moment reduction is in flight (me_pooled_moments_end first)");
   ME_HIP(e, hipSetDevice(e->device));
   hipError_t err = launch_pool_reduce(e->x, e->n, e->nr, e->nc, e->dtype, e->accept_slots, e->n_slots,
                                       (double)e->proposed, e->pool_partials, (double *)device_out, e->stream,
@@ -872,6 +880,37 @@ int me_pooled_moments(me_engine *e, double *host_out, int64_t n_doubles) {
   // through a pinned staging buffer: one asynchronous copy behind the kernels, one wait
   ME_HIP(e, hipMemcpyAsync(e->pool_host, e->pool_dev, sizeof(double) * (size_t)n_doubles, hipMemcpyDeviceToHost, e->stream));
   ME_HIP(e, hipStreamSynchronize(e->stream));
+  std::memcpy(host_out, e->pool_host, sizeof(double) * (size_t)n_doubles);
+  return ME_OK;
+}
+
+int me_pooled_moments_begin(me_engine *e) {
+  if (!e) return ME_ERR_INVALID;
+  if (e->pool_pending) return fail(e, ME_ERR_STATE, "a pooled-moment reduction is already in flight: call me_pooled_moments_end first");
+  ME_HIP(e, hipSetDevice(e->device));
+  if (!e->copy_stream) {
+    ME_HIP(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    ME_HIP(e, hipEventCreateWithFlags(&e->pool_reduced, hipEventDisableTiming));
+    ME_HIP(e, hipEventCreateWithFlags(&e->pool_copied, hipEventDisableTiming));
+  }
+  const int64_t n_doubles = moments_size(e->nr, e->nc);
+  int rc = enqueue_pooled_moments(e, e->pool_dev, n_doubles);
+  if (rc != ME_OK) return rc;
+  ME_HIP(e, hipEventRecord(e->pool_reduced, e->stream));
+  ME_HIP(e, hipStreamWaitEvent(e->copy_stream, e->pool_reduced, 0));
+  ME_HIP(e, hipMemcpyAsync(e->pool_host, e->pool_dev, sizeof(double) * (size_t)n_doubles, hipMemcpyDeviceToHost, e->copy_stream));
+  ME_HIP(e, hipEventRecord(e->pool_copied, e->copy_stream));
+  e->pool_pending = true;
+  return ME_OK;
+}
+
+int me_pooled_moments_end(me_engine *e, double *host_out, int64_t n_doubles) {
+  if (!e || !host_out) return ME_ERR_INVALID;
+  if (!e->pool_pending) return fail(e, ME_ERR_STATE, "no pooled-moment reduction in flight: call me_pooled_moments_begin first");
+  if (n_doubles != moments_size(e->nr, e->nc)) return fail(e, ME_ERR_INVALID, "wrong pooled-moment buffer length");
+  ME_HIP(e, hipSetDevice(e->device));
+  ME_HIP(e, hipEventSynchronize(e->pool_copied));
+  e->pool_pending = false;
   std::memcpy(host_out, e->pool_host, sizeof(double) * (size_t)n_doubles);
   return ME_OK;
 }

@@ -85,6 +85,20 @@ def pooled_statistics(engine, group=None):
     return moments_to_statistics(total, nr, nc)
 
 
+def pooled_statistics_begin(engine):
+    """Start the pooled reduction of the engine's current state without stalling its stream (see
+    ``me_pooled_moments_begin``); keep enqueuing steps, then call :func:`pooled_statistics_end`."""
+    engine.pooled_moments_begin()
+
+
+def pooled_statistics_end(engine, group=None):
+    """Collect the reduction started by :func:`pooled_statistics_begin`, all-reduce it over the ranks and convert it.
+    The GPU keeps executing whatever was enqueued in between, so the copy, the all-reduce and the host arithmetic
+    are off the sampler's critical path."""
+    total = allreduce_moments(engine.pooled_moments_end(), group)
+    return moments_to_statistics(total, engine.num_real_params, engine.num_complex_params)
+
+
 def pooled_factor(covariance, n_real, n_complex, jitter=0.0):
     """Packed proposal factor (ME_FIELD_FACTOR layout) from a pooled real-representation covariance [D, D].
 

@@ -411,6 +411,18 @@ class MetropolisEngine:
         self._check(self._lib.me_pooled_moments(self._handle, _as_double_ptr(out), size.value))
         return out
 
+    def pooled_moments_begin(self):
+        """Enqueue the pooled-moment reduction of the CURRENT state and its copy to the host without waiting; work
+        enqueued afterwards overlaps it.  Collect with :meth:`pooled_moments_end`."""
+        self._check(self._lib.me_pooled_moments_begin(self._handle))
+
+    def pooled_moments_end(self):
+        size = ctypes.c_int64()
+        self._check(self._lib.me_pooled_moments_size(self._handle, ctypes.byref(size)))
+        out = np.empty(size.value, dtype=np.float64)
+        self._check(self._lib.me_pooled_moments_end(self._handle, _as_double_ptr(out), size.value))
+        return out
+
     def pooled_moments_into(self, device_ptr, n_doubles):
         """Write the local ensemble sums into caller-owned device memory (e.g. a torch CUDA tensor's data_ptr)."""
         self._check(self._lib.me_pooled_moments_device(self._handle, ctypes.c_void_p(device_ptr), int(n_doubles)))

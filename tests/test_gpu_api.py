@@ -147,3 +147,31 @@ def test_largest_register_resident_dimension():
     assert np.allclose(eng.real_mean[0], (x[0] + 0.0) / 2, atol=1e-6)      # mean of the initial point and the state
     with pytest.raises(RuntimeError):
         me.MetropolisEngine(me.IsoQuadratic(a), initial_real_params=[0.0] * 97, temp=1.0, n_chains=64)
+
+
+def test_split_pooled_moments_report_the_state_at_begin():
+    """me_pooled_moments_begin/_end: the reduction is enqueued behind the work already queued, later steps overlap the
+    copy, and the result is the moment vector of the state AT begin -- bitwise the blocking call's."""
+    eng = me.MetropolisEngine(me.DiagQuadratic((1.0, 2.0), (3.0,)), None, [0.2, -0.1], [0.1 + 0.3j], temp=1.0,
+                              n_chains=(1 << 15) + 17, seed=3)
+    eng.step_all(25)
+    blocking = eng.pooled_moments()
+    eng.pooled_moments_begin()
+    with pytest.raises(RuntimeError):
+        eng.pooled_moments_begin()                 # one in flight per engine
+    with pytest.raises(RuntimeError):
+        eng.pooled_moments()
+    eng.step_all(40)                               # runs while the result travels; does not disturb it
+    eng.measure()
+    split = eng.pooled_moments_end()
+    assert np.array_equal(split, blocking)
+    with pytest.raises(RuntimeError):
+        eng.pooled_moments_end()
+    later = eng.pooled_moments()
+    assert later[-1] == blocking[-1] + 40 * eng.n_chains and not np.array_equal(later[1:5], blocking[1:5])
+    from metropolisengine_amd.distributed import pooled_statistics_begin, pooled_statistics_end, moments_to_statistics
+    pooled_statistics_begin(eng)
+    eng.step_all(3)
+    stats = pooled_statistics_end(eng)
+    want = moments_to_statistics(later, 2, 1)
+    assert np.array_equal(stats["covariance"], want["covariance"])

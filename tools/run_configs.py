@@ -14,7 +14,8 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import metropolisengine_amd as me  # noqa: E402
-from metropolisengine_amd.distributed import moments_to_statistics, pooled_statistics  # noqa: E402
+from metropolisengine_amd.distributed import (moments_to_statistics, pooled_statistics,  # noqa: E402
+                                              pooled_statistics_begin, pooled_statistics_end)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--configs", default="2,3,4,5")
@@ -23,13 +24,14 @@ args = ap.parse_args()
 out = {}
 
 
-def run(name, eng, n, steps_per_measure, n_measures, warm_measures=0, sweeps_fused=False, pooled=False):
+def run(name, eng, n, steps_per_measure, n_measures, warm_measures=0, sweeps_fused=False, pooled=False, overlap=False):
     for _ in range(warm_measures):
         eng.step_all(steps_per_measure)
         eng.measure()
     if pooled:
         pooled_statistics(eng)       # first call imports torch.distributed: keep that out of the timed region
     eng.sync()
+    pending = False
     t0 = time.perf_counter()
     for _ in range(n_measures):
         if sweeps_fused:
@@ -39,12 +41,19 @@ def run(name, eng, n, steps_per_measure, n_measures, warm_measures=0, sweeps_fus
                 eng.step_all()
         if steps_per_measure and name != "cfg2":
             eng.measure()
-        if pooled:      # config 5's protocol: the pooled moments every cycle (an RCCL all-reduce when ranks > 1)
+        if pooled and not overlap:   # config 5's protocol: the pooled moments every cycle (an RCCL all-reduce when ranks > 1)
             pooled_statistics(eng)
+        elif pooled:                 # same, but collected one cycle later so that the next cycle's steps hide it
+            if pending:
+                pooled_statistics_end(eng)
+            pooled_statistics_begin(eng)
+            pending = True
+    if pooled and overlap and pending:
+        pooled_statistics_end(eng)
     eng.sync()
     dt = time.perf_counter() - t0
     rate = n * steps_per_measure * n_measures / dt
-    name = name + ("_pooled" if pooled else "")
+    name = name + ("_pooled" if pooled else "") + ("_overlap" if overlap else "")
     out[name + ("_fused" if sweeps_fused else "")] = {"chain_steps_per_s": rate, "seconds": dt,
                                                         "acceptance": eng.acceptance_rate()}
     print("%-12s %.3e chain-steps/s  (%.3f s, acceptance %.3f)" % (name + ("_fused" if sweeps_fused else ""), rate, dt,
@@ -83,4 +92,5 @@ for cfg in [int(c) for c in args.configs.split(",")]:
                                       [0.1, 0.0], [0.05] * 7, temp=0.1, n_chains=n, seed=2026)
             run("cfg5", eng, n, 10, 200, warm_measures=60, sweeps_fused=fused)
             run("cfg5", eng, n, 10, 200, sweeps_fused=fused, pooled=True)
+            run("cfg5", eng, n, 10, 200, sweeps_fused=fused, pooled=True, overlap=True)
 print(json.dumps(out))
