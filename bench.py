@@ -42,6 +42,24 @@ def pmc_traffic(chains_log2, sweeps):
     return rec.get("traffic_bytes_per_launch")
 
 
+def issue_utilisation(torch, device, chain_sweeps_per_second):
+    """Fraction of the chip's vector-issue cycles the fused-sweep run occupies (fused sweeps are
+    instruction-bound, so this -- not the HBM fraction -- describes them).  Static VALU count of one sweep from the
+    newest profiles/r*_kernel_valu.json (tools/valu_count.py); a wave64 instruction holds a SIMD for 4 cycles."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_valu.json")))
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        valu = json.load(fh)["valu_instructions"]
+    props = torch.cuda.get_device_properties(device)
+    clock_hz = float(getattr(props, "clock_rate", 0)) * 1e3 or 2.4e9       # kHz; MI355X peak engine clock otherwise
+    simds = props.multi_processor_count * 4
+    busy = chain_sweeps_per_second / 64.0 * valu * 4.0
+    return {"valu_per_wavefront_sweep": valu, "simds": simds, "clock_GHz": clock_hz / 1e9,
+            "frac": busy / (simds * clock_hz)}
+
+
 def cpu_baseline(seconds):
     """Python restatement of the reference loop, one chain per process on the host cores (no GPU involved)."""
     cores = max(1, min(os.cpu_count() or 1, 16))
@@ -217,6 +235,9 @@ def main():
                  "value": float(n_local) * world * launches * args.fused_sweeps / fwall, "unit": "chain-steps/s",
                  "ms_per_launch": fdev / launches,
                  "effective_state_GBps": algorithmic / (fdev / launches * 1e-3) / 1e9}
+        if args.chains_log2 == 20 and world == 1:
+            fused["valu_issue"] = issue_utilisation(torch, local_rank,
+                                                    float(n_local) * launches * args.fused_sweeps / (fdev * 1e-3))
 
     stats = pooled_statistics(engine)                      # the one collective: RCCL all-reduce of pooled moments
     engine.sync()

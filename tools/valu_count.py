@@ -1,0 +1,53 @@
+"""Count the vector-ALU instructions one sweep of the headline kernel issues (static, from the compiler's assembly):
+the figure behind bench.py's fused-sweep "issue utilisation" (when sweeps are fused the kernel is
+instruction-bound and the HBM fraction no longer describes it).
+
+    python tools/valu_count.py > profiles/rNN_kernel_valu.json
+
+The sweep loop is the innermost loop of k_step<float,16,0,EnergyIso,identity>; every `v_*` instruction in it is
+counted once (MFMA excluded, none here), `s_*` separately.  A wave64 instruction occupies a SIMD's 16 lanes for 4
+cycles, so one wavefront-sweep needs >= 4 x count cycles of one SIMD.
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL = "_ZN2me6k_stepIfLi16ELi0ENS_9EnergyIsoIfLi16ELi0EEELi0ELb0ELi0EEEvNS_8StepArgsIT_EET2_"
+
+with tempfile.TemporaryDirectory() as tmp:
+    out = os.path.join(tmp, "k16.s")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                    "-DME_NR=16", "-DME_NC=0", "-DME_DENSE=1", "-DME_PER_CHAIN=1", "-S", "--cuda-device-only",
+                    os.path.join(ROOT, "metropolisengine_amd", "csrc", "me_kernels.hip"), "-o", out],
+                   check=True, stderr=subprocess.DEVNULL)
+    text = open(out).read()
+start = text.index(KERNEL + ":")
+body = text[start:text.index("s_endpgm", start)].splitlines()
+# the sweep loop: the inner loop with the largest body (the kernel's tail has a small one summing nothing of interest)
+best = None
+for i, line in enumerate(body):
+    if "Inner Loop Header" not in line:
+        continue
+    j = i if body[i].startswith(".LBB") else i - 1
+    label = re.match(r"(\.LBB\d+_\d+):", body[j]).group(1)
+    ends = [k for k, l in enumerate(body) if k > j and re.search(r"s_cbranch\w*\s+" + re.escape(label) + r"\b", l)]
+    if ends and (best is None or ends[-1] - j > best[1] - best[0]):
+        best = (j, ends[-1])
+if best is None:
+    sys.exit("no inner loop found")
+head, end = best
+loop = [line.split()[0] for line in body[head:end + 1] if line.strip() and not line.strip().startswith((";", "."))]
+valu = [op for op in loop if op.startswith("v_")]
+salu = [op for op in loop if op.startswith("s_") and not op.startswith(("s_waitcnt", "s_nop", "s_cbranch"))]
+mem = [op for op in loop if op.startswith(("buffer_", "global_", "ds_", "scratch_", "flat_"))]
+top = {}
+for op in valu:
+    top[op] = top.get(op, 0) + 1
+print(json.dumps({"kernel": "k_step<float,16,0,EnergyIso,identity>", "scope": "one sweep (innermost loop body)",
+                  "valu_instructions": len(valu), "salu_instructions": len(salu), "memory_instructions": len(mem),
+                  "cycles_per_wavefront_sweep_lower_bound": 4 * len(valu),
+                  "most_frequent": sorted(top.items(), key=lambda kv: -kv[1])[:8]}, indent=1))
