@@ -625,24 +625,42 @@ __global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
   __shared__ R s_delta[STREAM ? D : 1][kStepThreads];
   for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
+    // Every phase issues ALL its loads before its first store: the compiler cannot prove that a store to one field does
+    // not alias the next load of another, so interleaved load-update-store sequences were emitted strictly in order
+    // with two loads in flight per wavefront (k_measure<64,0> ran at 0.36 of the HBM peak that way).
     R x[D], delta[D];
+    {
+      R mu[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      x[d] = fx.load(d, coff);
-      const R mu = fmean.load(d, coff);
-      if constexpr (STREAM) s_delta[d][threadIdx.x] = x[d] - mu;   // parked in LDS, see the streaming path below
-      else delta[d] = x[d] - mu;
-      fmean.store(d, coff, mu * a.keep + x[d] * a.inv_i);   // :404-410
+      for (int d = 0; d < D; ++d) x[d] = fx.load(d, coff);
+#pragma unroll
+      for (int d = 0; d < D; ++d) mu[d] = fmean.load(d, coff);
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        if constexpr (STREAM) s_delta[d][threadIdx.x] = x[d] - mu[d];   // parked in LDS, see the streaming path below
+        else delta[d] = x[d] - mu[d];
+        fmean.store(d, coff, mu[d] * a.keep + x[d] * a.inv_i);   // :404-410
+      }
     }
-    // observables [|x_r|, |z_c|, x_r^2] and their running mean (:458-463, :412-414)
+    // observables [|x_r|, |z_c|, x_r^2] and their running mean (:458-463, :412-414), in batches of kBatch
+    constexpr int kBatch = 32;
 #pragma unroll
-    for (int k = 0; k < NOBS; ++k) {
-      R o;
-      if (k < NR) o = N_::abs_(x[k]);
-      else if (k < NR + NC) o = N_::sqrt_(x[k] * x[k] + x[k + NC] * x[k + NC]);
-      else o = x[k - NR - NC] * x[k - NR - NC];
-      const R m = fobs.load(k, coff);
-      fobs.store(k, coff, m * a.keep + o * a.inv_i);
+    for (int k0 = 0; k0 < NOBS; k0 += kBatch) {
+      R m[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u)
+        if (k0 + u < NOBS) m[u] = fobs.load(k0 + u, coff);
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int k = k0 + u;
+        if (k < NOBS) {
+          R o;
+          if (k < NR) o = N_::abs_(x[k]);
+          else if (k < NR + NC) o = N_::sqrt_(x[k] * x[k] + x[k + NC] * x[k + NC]);
+          else o = x[k - NR - NC] * x[k - NR - NC];
+          fobs.store(k, coff, m[u] * a.keep + o * a.inv_i);
+        }
+      }
     }
     if constexpr (PER_CHAIN_COV) {
       if (a.update_cov) {
@@ -690,13 +708,16 @@ __global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
             p += a.n;
           }
         } else {
+        // the packed matrix is read whole, then updated and written back (FUSED keeps it for the Cholesky anyway)
         R m[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k) m[k] = fcov.load(k, coff);
 #pragma unroll
         for (int i = 0; i < NR; ++i)
 #pragma unroll
           for (int j = 0; j <= i; ++j) {
             const int k = tri(i, j);
-            R v = fcov.load(k, coff) * a.cov_keep + delta[i] * delta[j] * a.inv_i;
+            R v = m[k] * a.cov_keep + delta[i] * delta[j] * a.inv_i;
             if (i == j) v += eps;
             fcov.store(k, coff, v);
             m[k] = v;
@@ -708,15 +729,15 @@ __global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
           for (int j = 0; j < i; ++j) {
             const R aj = delta[NR + j], bj = delta[NR + NC + j];
             const int kr = cre(PR, i, j), ki = cim(PR, i, j);
-            const R vr = fcov.load(kr, coff) * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
-            const R vi = fcov.load(ki, coff) * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
+            const R vr = m[kr] * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
+            const R vi = m[ki] * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
             fcov.store(kr, coff, vr);
             fcov.store(ki, coff, vi);
             m[kr] = vr;
             m[ki] = -vi;   // the proposals use conj(K) (quirk Q3, :292-298)
           }
           const int kd = cdiag(PR, i);
-          const R vd = fcov.load(kd, coff) * a.cov_keep + (ai * ai + bi * bi) * a.inv_i + eps_c;
+          const R vd = m[kd] * a.cov_keep + (ai * ai + bi * bi) * a.inv_i + eps_c;
           fcov.store(kd, coff, vd);
           m[kd] = vd;
         }
