@@ -678,15 +678,23 @@ __global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
           for (int i = 0; i < NR; ++i) {
             const R di = s_delta[i][threadIdx.x];
             int j = 0;
-            // batches of 8 entries: all loads first (a store to p[.] would otherwise fence the next load, the compiler
+            // batches of 16 (then 4) entries: all loads first (a store to p[.] would otherwise fence the next load, the compiler
             // cannot prove the rows distinct), then the updates
-            for (; j + 8 <= i; j += 8) {
-              R v[8];
+            for (; j + 16 <= i; j += 16) {
+              R v[16];
 #pragma unroll
-              for (int u = 0; u < 8; ++u) v[u] = p[u * a.n];
+              for (int u = 0; u < 16; ++u) v[u] = p[u * a.n];
 #pragma unroll
-              for (int u = 0; u < 8; ++u) p[u * a.n] = v[u] * a.cov_keep + di * s_delta[j + u][threadIdx.x] * a.inv_i;
-              p += 8 * a.n;
+              for (int u = 0; u < 16; ++u) p[u * a.n] = v[u] * a.cov_keep + di * s_delta[j + u][threadIdx.x] * a.inv_i;
+              p += 16 * a.n;
+            }
+            for (; j + 4 <= i; j += 4) {
+              R v[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) v[u] = p[u * a.n];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) p[u * a.n] = v[u] * a.cov_keep + di * s_delta[j + u][threadIdx.x] * a.inv_i;
+              p += 4 * a.n;
             }
             for (; j < i; ++j) {
               *p = *p * a.cov_keep + di * s_delta[j][threadIdx.x] * a.inv_i;
