@@ -29,7 +29,7 @@
 #define ME_TRACK_COV 1   // k_measure can maintain the per-chain running covariance (streaming form when ME_PER_CHAIN=0)
 #endif
 #ifndef ME_MEASURE_FUSED_MAX_P
-#define ME_MEASURE_FUSED_MAX_P 56   // largest packed size whose Cholesky is fused into k_measure ((2,7): 52 fused; (16,0): 136 split)
+#define ME_MEASURE_FUSED_MAX_P 160   // largest packed size whose Cholesky is fused into k_measure (all per-chain kernel sets; k_factor stays as the split form)
 #endif
 
 namespace me {
