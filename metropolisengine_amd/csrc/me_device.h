@@ -604,9 +604,10 @@ __device__ __forceinline__ void cholesky_packed(R (&m)[NR * (NR + 1) / 2 + NC * 
     }
 }
 
-// FUSED = true refreshes the proposal factors in the same kernel (the updated covariance stays in registers); for
-// large packed sizes that costs occupancy on the streaming part (16 real parameters: 236 VGPRs, 2 wavefronts per
-// SIMD, 2.2 TB/s), so there the factors are refreshed by k_factor in a second launch (FUSED = false).
+// FUSED = true refreshes the proposal factors in the same kernel (the updated covariance stays in registers).  With the
+// loads of every phase batched ahead of its stores this is the faster form for every per-chain kernel set, 16 real
+// parameters (136 entries, 253 VGPRs, two wavefronts per SIMD) included: 460 us against 570 us for the split form
+// (FUSED = false followed by k_factor), which is kept for experiments (-DME_MEASURE_FUSED_MAX_P).
 template <typename R, int NR, int NC, bool PER_CHAIN_COV, bool FUSED>
 __global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
   constexpr int D = NR + 2 * NC;

@@ -67,7 +67,7 @@ for _ in range(55):
     eng.step_all(2); eng.measure()
 p = packed(16, 0)
 add("k_step (16,0) per-chain factor", 144 + 4 * p, n, step_us(eng, 100))
-add("k_measure + k_factor (16,0)", 4 * 16 + 4 + 8 * 16 + 8 * 32 + 12 * p + 4 * p, n, measure_us(eng))
+add("k_measure (16,0), fused Cholesky", 4 * 16 + 4 + 8 * 16 + 8 * 32 + 12 * p, n, measure_us(eng))
 del eng
 # config 3
 a = b = (1.0, 2.0, 4.0, 8.0)
