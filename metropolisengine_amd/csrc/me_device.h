@@ -706,11 +706,24 @@ __global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
           }
           for (int i = 0; i < NC; ++i) {
             const R ai = s_delta[NR + i][threadIdx.x], bi = s_delta[NR + NC + i][threadIdx.x];
-#pragma unroll 4
-            for (int j = 0; j < i; ++j) {
+            int j = 0;
+            for (; j + 8 <= i; j += 8) {          // eight (Re, Im) pairs: sixteen loads, then the updates
+              R v[16];
+#pragma unroll
+              for (int u = 0; u < 16; ++u) v[u] = p[u * a.n];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                const R aj = s_delta[NR + j + u][threadIdx.x], bj = s_delta[NR + NC + j + u][threadIdx.x];
+                p[(2 * u) * a.n] = v[2 * u] * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
+                p[(2 * u + 1) * a.n] = v[2 * u + 1] * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
+              }
+              p += 16 * a.n;
+            }
+            for (; j < i; ++j) {
               const R aj = s_delta[NR + j][threadIdx.x], bj = s_delta[NR + NC + j][threadIdx.x];
-              p[0] = p[0] * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
-              p[a.n] = p[a.n] * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
+              const R re = p[0], im = p[a.n];
+              p[0] = re * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
+              p[a.n] = im * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
               p += 2 * a.n;
             }
             *p = *p * a.cov_keep + (ai * ai + bi * bi) * a.inv_i + eps_c;
