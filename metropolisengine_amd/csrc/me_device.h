@@ -147,10 +147,16 @@ struct EnergyIso {  // a (sum x^2 + sum |z|^2)                                  
   static constexpr int D = NR + 2 * NC;
   R a;
   __device__ __forceinline__ R operator()(const R (&x)[D]) const {
-    R s = 0;
+    // two interleaved partial sums: independent fma chains that pair up as v_pk_fma_f32 (one chain compiled to
+    // 8 v_pk_mul + 15 dependent v_add at D = 16)
+    R s0 = 0, s1 = 0;
 #pragma unroll
-    for (int d = 0; d < D; ++d) s += x[d] * x[d];
-    return a * s;
+    for (int d = 0; d + 1 < D; d += 2) {
+      s0 += x[d] * x[d];
+      s1 += x[d + 1] * x[d + 1];
+    }
+    if constexpr (D % 2 == 1) s0 += x[D - 1] * x[D - 1];
+    return a * (s0 + s1);
   }
 };
 
@@ -484,8 +490,25 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
       if (a.temp > R(0)) accept = accept || N_::uphill(u, diff, a.temp, a.inv_temp_log2e);
       accept = accept && !rejected;
       bad_energy |= (!rejected && !N_::finite(e_new));
+      if constexpr (CK == CK_IDENTITY) {
+        // commit as x += (accept ? w : 0) g: the same fma that formed x' (bit-identical on acceptance, exact identity on
+        // rejection since the draws are finite), and it pairs up as v_pk_fma_f32 where 16 v_cndmask_b32 would not
+        const R wa_r = accept ? w_r : R(0), wa_c = accept ? w_c : R(0);
+        if constexpr (MOVE_REAL) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) x[d] = accept ? xp[d] : x[d];
+          for (int i = 0; i < NR; ++i) x[i] = x[i] + wa_r * g[i];
+        }
+        if constexpr (MOVE_COMPLEX) {
+#pragma unroll
+          for (int j = 0; j < NC; ++j) {
+            x[NR + j] = x[NR + j] + wa_c * (g[NR + j] * R(0.70710678118654752440));
+            x[NR + NC + j] = x[NR + NC + j] + wa_c * (g[NR + NC + j] * R(0.70710678118654752440));
+          }
+        }
+      } else {
+#pragma unroll
+        for (int d = 0; d < D; ++d) x[d] = accept ? xp[d] : x[d];
+      }
       ledger.commit(accept, terms_new);
       // ---- Robbins-Monro width update (:429-456); step_all of a mixed engine mirrors it into both groups (:436-437)
       w = N_::adapt(w, accept, a.ratio, a.p, a.damping, a.up, a.down);
