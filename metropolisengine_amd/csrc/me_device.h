@@ -165,10 +165,14 @@ struct EnergyDiag {  // sum a_i x_i^2 + sum b_j |z_j|^2; weights expanded to D e
   static constexpr int D = NR + 2 * NC;
   R w[D];
   __device__ __forceinline__ R operator()(const R (&x)[D]) const {
-    R s = 0;
+    R s0 = 0, s1 = 0;   // two interleaved chains (see EnergyIso)
 #pragma unroll
-    for (int d = 0; d < D; ++d) s += w[d] * x[d] * x[d];
-    return s;
+    for (int d = 0; d + 1 < D; d += 2) {
+      s0 += w[d] * x[d] * x[d];
+      s1 += w[d + 1] * x[d + 1] * x[d + 1];
+    }
+    if constexpr (D % 2 == 1) s0 += w[D - 1] * x[D - 1] * x[D - 1];
+    return s0 + s1;
   }
 };
 
