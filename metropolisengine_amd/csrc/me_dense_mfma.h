@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(kDenseBlockThreads, 2) k_step_dense64_mfma(Ste
       if (a.reject_kind == ME_REJECT_ABS_REAL0_GE) rejected = !(N_::abs_(lds_xp[0]) < a.reject_bound);
       const float diff = e_new - e;
       bool accept = diff <= 0.0f;
-      if (a.temp > 0.0f) accept = accept || N_::uphill(u, diff, a.temp, a.inv_temp_log2e);
+      if (a.temp > 0.0f) accept = accept || N_::uphill(u, diff, a.inv_temp, a.inv_temp_log2e);
       accept = accept && !rejected;
       bad_energy |= (live && !rejected && !N_::finite(e_new));
       if (accept) {

@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "me_internal.h"
+#include "me_math64.h"
 
 namespace me {
 
@@ -54,6 +55,7 @@ template <>
 struct Num<float> {
   // u = (w + 0.5) 2^-32 in (0, 1]; Box-Muller with the hardware transcendentals: v_log_f32 is log2,
   // v_sin_f32 / v_cos_f32 take their argument in revolutions, which is exactly 2*pi*u2.
+  static __device__ __forceinline__ void prepare() {}
   static __device__ __forceinline__ float unit(uint32_t w) {
     return __builtin_fmaf((float)w, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
   }
@@ -64,7 +66,7 @@ struct Num<float> {
     g1 = r * __builtin_amdgcn_sinf(u2);
   }
   // accept an uphill move of size d > 0:  u <= exp(-d/T)
-  static __device__ __forceinline__ bool uphill(float u, float d, float temp, float inv_temp_log2e) {
+  static __device__ __forceinline__ bool uphill(float u, float d, float, float inv_temp_log2e) {
     return u <= __builtin_amdgcn_exp2f(-d * inv_temp_log2e);
   }
   static __device__ __forceinline__ float adapt(float w, bool acc, float ratio, float p, float damping,
@@ -78,18 +80,29 @@ struct Num<float> {
 
 template <>
 struct Num<double> {
+  // The float64 Box-Muller / accept arithmetic is me_math64.h (range-specific log, sqrt, sin/cos, exp; <= 4 ulp): the
+  // general-purpose device libm versions cost 2.5x the instructions and 180 VGPRs in k_step.  Its 97-row log table
+  // (1.5 KiB) lives in LDS: the lookups are per-lane gathers, LDS serves them without touching the vector-memory
+  // queue the state rows are arriving on.
+  static __device__ __forceinline__ double (*log_table())[2] {
+    __shared__ __attribute__((aligned(16))) double table[math64::kLogEntries][2];
+    return table;
+  }
+  // once per block, by every thread, before the first normal_pair
+  static __device__ __forceinline__ void prepare() {
+    double(*table)[2] = log_table();
+    for (int k = threadIdx.x; k < math64::kLogEntries; k += blockDim.x) {
+      table[k][0] = math64::kLogTable[k][0];
+      table[k][1] = math64::kLogTable[k][1];
+    }
+    __syncthreads();
+  }
   static __device__ __forceinline__ double unit(uint32_t w) { return ((double)w + 0.5) * (1.0 / 4294967296.0); }
   static __device__ __forceinline__ void normal_pair(uint32_t wa, uint32_t wb, double &g0, double &g1) {
-    const double u1 = unit(wa), u2 = unit(wb);
-    const double r = sqrt(-2.0 * log(u1));
-    const double theta = 6.283185307179586 * u2;
-    double sn, cs;
-    sincos(theta, &sn, &cs);      // one argument reduction for both (same values as sin() and cos())
-    g0 = r * cs;
-    g1 = r * sn;
+    math64::normal_pair(wa, wb, log_table(), g0, g1);
   }
-  static __device__ __forceinline__ bool uphill(double u, double d, double temp, double) {
-    return u <= exp(-d / temp);
+  static __device__ __forceinline__ bool uphill(double u, double d, double inv_temp, double) {
+    return u <= math64::exp_nonpos(-d * inv_temp);
   }
   // literal order of metropolis_engine.py:431-435 so that trajectories track the float64 oracle
   static __device__ __forceinline__ double adapt(double w, bool acc, double ratio, double p, double damping,
@@ -339,7 +352,7 @@ struct StepArgs {
   uint32_t seed_lo, seed_hi;
   int n_sweeps, reject_kind;
   int split_widths;   // mixed engines: group widths (rows 1, 2) differ from the shared width (row 0)
-  R reject_bound, temp, inv_temp_log2e, ratio, p, damping, up, down;
+  R reject_bound, temp, inv_temp, inv_temp_log2e, ratio, p, damping, up, down;
 };
 
 // packed index of element (i, j), j <= i, of a row-major lower triangle
@@ -379,6 +392,7 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   static_assert(GROUP == GROUP_ALL || MIXED, "group-wise kernels exist for mixed engines only");
   using N_ = Num<R>;
 
+  if constexpr (!INJECT) N_::prepare();
   unsigned int wave_accepted = 0;
   bool bad_energy = false, bad_width = false;
   const long long stride = (long long)gridDim.x * blockDim.x;   // 64 threads per block, or 256 for fused sweeps
@@ -491,7 +505,7 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
       const R e_new = ledger.propose(en, xp, terms_new);
       const R diff = e_new - ledger.partial();
       bool accept = diff <= R(0);
-      if (a.temp > R(0)) accept = accept || N_::uphill(u, diff, a.temp, a.inv_temp_log2e);
+      if (a.temp > R(0)) accept = accept || N_::uphill(u, diff, a.inv_temp, a.inv_temp_log2e);
       accept = accept && !rejected;
       bad_energy |= (!rejected && !N_::finite(e_new));
       if constexpr (CK == CK_IDENTITY) {

@@ -141,6 +141,7 @@ StepArgs<R> typed(const StepLaunch &l) {
   a.split_widths = l.split_widths;
   a.reject_bound = (R)l.reject_bound;
   a.temp = (R)l.temp;
+  a.inv_temp = l.temp > 0 ? (R)(1.0 / l.temp) : (R)0;
   a.inv_temp_log2e = l.temp > 0 ? (R)(1.4426950408889634 / l.temp) : (R)0;
   a.ratio = (R)l.ratio;
   a.p = (R)l.target_acceptance;

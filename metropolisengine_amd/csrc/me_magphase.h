@@ -49,6 +49,7 @@ __global__ void __launch_bounds__(kStepThreads) k_step_magphase(StepArgs<R> a, E
   constexpr int WROW = MIXED ? GROUP_COMPLEX : 0;
   using N_ = Num<R>;
 
+  if constexpr (!INJECT) N_::prepare();
   unsigned int wave_accepted = 0;
   bool bad_energy = false, bad_width = false;
   const long long stride = (long long)gridDim.x * kStepThreads;
@@ -75,7 +76,7 @@ __global__ void __launch_bounds__(kStepThreads) k_step_magphase(StepArgs<R> a, E
       const R e_new = ledger.propose(en, xp, terms_new);
       const R diff = e_new - ledger.partial();
       bool accept = diff <= R(0);
-      if (a.temp > R(0)) accept = accept || N_::uphill(u, diff, a.temp, a.inv_temp_log2e);
+      if (a.temp > R(0)) accept = accept || N_::uphill(u, diff, a.inv_temp, a.inv_temp_log2e);
       accept = accept && !rejected;
       bad_energy |= (!rejected && !N_::finite(e_new));
 #pragma unroll

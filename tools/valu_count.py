@@ -16,7 +16,8 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "_ZN2me6k_stepIfLi16ELi0ENS_9EnergyIsoIfLi16ELi0EEELi0ELb0ELi0EEEvNS_8StepArgsIT_EET2_"
+DTYPE = "d" if "--f64" in sys.argv else "f"        # --f64: the reference-precision instantiation
+KERNEL = "_ZN2me6k_stepI%sLi16ELi0ENS_9EnergyIsoI%sLi16ELi0EEELi0ELb0ELi0EEEvNS_8StepArgsIT_EET2_" % (DTYPE, DTYPE)
 
 with tempfile.TemporaryDirectory() as tmp:
     out = os.path.join(tmp, "k16.s")
@@ -47,7 +48,7 @@ mem = [op for op in loop if op.startswith(("buffer_", "global_", "ds_", "scratch
 top = {}
 for op in valu:
     top[op] = top.get(op, 0) + 1
-print(json.dumps({"kernel": "k_step<float,16,0,EnergyIso,identity>", "scope": "one sweep (innermost loop body)",
+print(json.dumps({"kernel": "k_step<%s,16,0,EnergyIso,identity>" % ("double" if DTYPE == "d" else "float"), "scope": "one sweep (innermost loop body)",
                   "valu_instructions": len(valu), "salu_instructions": len(salu), "memory_instructions": len(mem),
                   "cycles_per_wavefront_sweep_lower_bound": 4 * len(valu),
-                  "most_frequent": sorted(top.items(), key=lambda kv: -kv[1])[:8]}, indent=1))
+                  "most_frequent": sorted(top.items(), key=lambda kv: -kv[1])[:16 if DTYPE == "d" else 8]}, indent=1))
