@@ -10,6 +10,11 @@ sampling_width 0.05, target acceptance 0.3, seed 2026, identity proposal shape (
 One "step" = one ``step_all()`` = ONE launch of k_step advancing every chain by one propose -> energy ->
 accept/reject -> width-adaptation sweep (``--sweeps K`` fuses K sweeps per launch; reported separately as
 ``fused``).  State is resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+The top-level ``value`` / ``dtype`` / ``roofline`` are the FLOAT64 run: float64 / complex128 is the reference's
+arithmetic (metropolis_engine.py:41, :51), 288 B of state traffic per chain-step.  The float32 build of the same
+kernels (144 B per chain-step, the production dtype) is the sibling block ``f32``.  ``roofline_hbm`` is the same
+float64 kernel at 2^22 chains, where the state (604 MB) no longer fits the 256 MiB Infinity Cache.
 """
 import argparse
 import json
@@ -25,21 +30,27 @@ if ROOT not in sys.path:
 N_REAL = 16
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 BYTES_PER_CHAIN_STEP = 8 * N_REAL + 16   # fp32 r/w of x[16], energy, width: SURVEY.md 8(d), B_step(identity) = 144 B
+BYTES_PER_CHAIN_STEP_F64 = 2 * BYTES_PER_CHAIN_STEP   # "fp64 state doubles every term"  = 288 B
+INFINITY_CACHE_BYTES = 256 << 20
+SIDE_LAUNCHES = 300                      # launches of every side measurement (independent of --steps)
 
 
-def pmc_traffic(chains_log2, sweeps):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r*_pmc_traffic.json): FETCH_SIZE
-    (x2, gfx950 correction) + WRITE_SIZE, separate passes.  PMC collection cannot run inside the timed bench, so
-    the figure is taken from the newest committed pass of this same workload; None for any other workload."""
-    if chains_log2 != 20 or sweeps != 1:
-        return None
+def pmc_traffic(dtype, chains_log2, sweeps):
+    """(HBM bytes per launch, source file) from the committed rocprofv3 --pmc passes (profiles/r*_pmc_traffic_<dtype>
+    .json): FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes.  PMC collection cannot run inside the
+    timed bench, so the figure is a COMMITTED measurement of this same workload (the file is named in
+    ``traffic_source``); (None, None) for any other workload."""
+    if sweeps != 1:
+        return None, None
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s_2p%d.json" % (dtype, chains_log2))))
+    if not files and dtype == "f32" and chains_log2 == 20:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))      # round-1 name
     if not files:
-        return None
+        return None, None
     with open(files[-1]) as fh:
         rec = json.load(fh)
-    return rec.get("traffic_bytes_per_launch")
+    return rec.get("traffic_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
 
 
 def issue_utilisation(torch, device, chain_sweeps_per_second):
@@ -47,7 +58,7 @@ def issue_utilisation(torch, device, chain_sweeps_per_second):
     instruction-bound, so this -- not the HBM fraction -- describes them).  Static VALU count of one sweep from the
     newest profiles/r*_kernel_valu.json (tools/valu_count.py); a wave64 instruction holds a SIMD for 4 cycles."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_valu.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_valu.json")))
     if not files:
         return None
     with open(files[-1]) as fh:
@@ -60,9 +71,44 @@ def issue_utilisation(torch, device, chain_sweeps_per_second):
             "frac": busy / (simds * clock_hz)}
 
 
+def cgroup_cpu_quota():
+    """CPUs this process group may use according to its cgroup (v2 ``cpu.max`` / v1 ``cpu.cfs_quota_us``); None when
+    unlimited.  A one-GPU box of the pool shows all 256 host CPUs but grants a 16-CPU share this way."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            return max(1, int(float(quota) / float(period) + 0.5))
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+            quota, period = int(fq.read()), int(fp.read())
+        if quota > 0:
+            return max(1, int(quota / period + 0.5))
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def host_cores():
+    """Cores the CPU baselines use: ALL the cores this process is allowed -- the smaller of its affinity mask and its
+    cgroup CPU quota (more runnable processes than the quota only thrash) -- unless METROPOLIS_BENCH_CPU_CORES caps it.
+    The JSON states this number next to os.cpu_count() and the quota."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        avail = os.cpu_count() or 1
+    quota = cgroup_cpu_quota()
+    if quota:
+        avail = min(avail, quota)
+    cap = int(os.environ.get("METROPOLIS_BENCH_CPU_CORES", "0"))
+    return max(1, min(avail, cap) if cap > 0 else avail)
+
+
 def cpu_baseline(seconds):
     """Python restatement of the reference loop, one chain per process on the host cores (no GPU involved)."""
-    cores = max(1, min(os.cpu_count() or 1, 16))
+    cores = host_cores()
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_baseline", "--seconds", str(seconds),
                                "--seed", str(100 + i)], cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
@@ -72,7 +118,8 @@ def cpu_baseline(seconds):
         out, _ = p.communicate()
         rec = json.loads(out.strip().splitlines()[-1])
         rate += rec["steps"] / rec["seconds"]
-    return {"value": rate, "unit": "chain-steps/s", "cores": cores, "kind": "port",
+    return {"value": rate, "unit": "chain-steps/s", "cores": cores, "host_cpu_count": os.cpu_count(),
+            "cgroup_cpu_quota": cgroup_cpu_quota(), "kind": "port",
             "sample": "oracle.reference_chain (pure-Python restatement of the reference step_all loop with "
                       "np.random.multivariate_normal), config 2 (16 real, E=sum x^2, T=1), one chain per process "
                       "on %d cores for %.0f s each; steps/s summed" % (cores, seconds)}
@@ -82,7 +129,7 @@ def cpu_baseline_c(seconds):
     """The plain-C restatement (oracle/c/me_oracle.c, float64, OpenMP over chains) on config 2: the strong CPU
     baseline next to the Python port.  Same Philox streams and arithmetic as the float64 GPU kernels."""
     from oracle.c_oracle import COracle
-    cores = max(1, min(os.cpu_count() or 1, 16))
+    cores = host_cores()
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     n = 1 << 16
     chains = COracle(N_REAL, 0, a=[1.0] * N_REAL, n_chains=n, seed=2026, temp=1.0, initial_real_params=[0.0] * N_REAL)
@@ -93,24 +140,19 @@ def cpu_baseline_c(seconds):
         chains.step(50)
         done += 50
     dt = time.perf_counter() - t0
-    return {"value": n * done / dt, "unit": "chain-steps/s", "cores": cores, "kind": "port",
+    return {"value": n * done / dt, "unit": "chain-steps/s", "cores": cores, "host_cpu_count": os.cpu_count(),
+            "cgroup_cpu_quota": cgroup_cpu_quota(), "kind": "port",
             "sample": "oracle/c/me_oracle.c (float64, OpenMP), config 2 with 2^16 chains x %d sweeps in %.1f s, "
                       "acceptance %.3f" % (done, dt, chains.accepted / chains.proposed)}
 
 
 def other_configs(me, device, chains_log2):
-    """Informational side measurements (not the headline): the float64 build of the same kernel and the protocols of
-    BASELINE.json configs 3-5, each through the public API incl. measure() launches."""
+    """Informational side measurements (not the headline): the protocols of BASELINE.json configs 3-5,
+    each through the public API incl. measure() launches; config 4 in float32 (split-bf16 matrix cores) and float64
+    (v_mfma_f64_16x16x4_f64)."""
     import numpy as np
     out = {}
     n = 1 << chains_log2
-    f64 = me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * N_REAL, None, temp=1.0, n_chains=n, seed=2026,
-                              dtype="f64", device=device)
-    f64.time_steps(50, 1)
-    ms = f64.time_steps(200, 1) / 200
-    out["config2_f64"] = {"chain_steps_per_s": n / (ms * 1e-3), "ms_per_launch": ms,
-                          "state_GBps": 2 * BYTES_PER_CHAIN_STEP * n / (ms * 1e-3) / 1e9}
-    del f64
 
     def protocol(engine, n_chains, steps_per_measure, cycles, warm_cycles):
         for _ in range(warm_cycles):
@@ -129,21 +171,49 @@ def other_configs(me, device, chains_log2):
                 "protocol": "(%d x step_all + measure) x %d" % (steps_per_measure, cycles)}
 
     a = b = (1.0, 2.0, 4.0, 8.0)
-    out["config3"] = protocol(me.MetropolisEngine(me.DiagQuadratic(a, b), None, [0.0] * 4, [0j] * 4, temp=1.0, n_chains=n,
-                                                  seed=2026, device=device), n, 10, 100, 60)
+    for dtype in ("f32", "f64"):
+        out["config3" + ("" if dtype == "f32" else "_f64")] = protocol(
+            me.MetropolisEngine(me.DiagQuadratic(a, b), None, [0.0] * 4, [0j] * 4, temp=1.0, n_chains=n, seed=2026,
+                                dtype=dtype, device=device), n, 10, 100, 60)
     m = np.random.default_rng(5).standard_normal((64, 64))
-    e4 = me.MetropolisEngine(me.DenseQuadratic(m @ m.T / 64 + np.identity(64)), None, [0.0] * 64, None, temp=1.0,
-                             n_chains=n // 2, seed=2026, cov_mode="fixed", device=device)
-    e4.time_steps(50, 1)
-    ms = e4.time_steps(100, 1) / 100
-    out["config4"] = {"chain_steps_per_s": (n // 2) / (ms * 1e-3), "ms_per_launch": ms, "chains": n // 2,
-                      "state_GBps": (8 * 64 + 16) * (n // 2) / (ms * 1e-3) / 1e9, "kernel": "k_step_dense64_bf16x3"}
-    del e4
+    for dtype, kernel, state_bytes in (("f32", "k_step_dense64_bf16x3", 8 * 64 + 16), ("f64", "k_step_dense64_f64", 16 * 64 + 32)):
+        try:
+            e4 = me.MetropolisEngine(me.DenseQuadratic(m @ m.T / 64 + np.identity(64)), None, [0.0] * 64, None, temp=1.0,
+                                     n_chains=n // 2, seed=2026, cov_mode="fixed", dtype=dtype, device=device)
+            e4.time_steps(30, 1)
+            ms = e4.time_steps(100, 1) / 100
+            out["config4" + ("" if dtype == "f32" else "_f64")] = {
+                "chain_steps_per_s": (n // 2) / (ms * 1e-3), "ms_per_launch": ms, "chains": n // 2,
+                "state_GBps": state_bytes * (n // 2) / (ms * 1e-3) / 1e9, "kernel": kernel, "dtype": dtype}
+            del e4
+        except Exception as exc:                        # a side measurement must not sink the headline line
+            out["config4" + ("" if dtype == "f32" else "_f64")] = {"error": repr(exc)}
     src = os.path.join(ROOT, "examples", "user_energy_cylinder.h")
     out["config5"] = protocol(me.MetropolisEngine(me.UserEnergy("cylinder", src, (1.0, 0.5, 1.0)),
                                                   me.AbsReal0AtLeast(1.0), [0.1, 0.0], [0.05] * 7, temp=0.1,
                                                   n_chains=n // 4, seed=2026, device=device), n // 4, 10, 100, 60)
     return out
+
+
+def roofline_block(dtype, chains_log2, kernel_ms, bound):
+    """The roofline object of one k_step<dtype,16,0,EnergyIso,identity> measurement (one sweep per launch)."""
+    per_step = BYTES_PER_CHAIN_STEP_F64 if dtype == "f64" else BYTES_PER_CHAIN_STEP
+    algorithmic = per_step * (1 << chains_log2)
+    achieved = algorithmic / (kernel_ms * 1e-3) / 1e9
+    traffic, source = pmc_traffic(dtype, chains_log2, 1)
+    word = "double" if dtype == "f64" else "float"
+    return {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic, "traffic_source": source, "kernel": "k_step<%s,16,0,EnergyIso,identity>" % word,
+            "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algorithmic,
+            "state_bytes_resident": algorithmic // 2,
+            "note": "%d B per chain-step (%s r/w of x[16], energy, width) x 2^%d chains / average launch duration from "
+                    "HIP events on the engine's stream over the timed region; traffic = FETCH_SIZE x2 + WRITE_SIZE of "
+                    "the committed rocprofv3 passes named in traffic_source (not measured in this run)"
+                    % (per_step, "fp64" if dtype == "f64" else "fp32", chains_log2)}
+
+
+def bound_label(state_bytes):
+    return "hbm+infinity-cache" if state_bytes <= INFINITY_CACHE_BYTES else "hbm"
 
 
 def main():
@@ -152,11 +222,13 @@ def main():
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--chains-log2", type=int, default=20, help="chains per GPU = 2**this")
+    ap.add_argument("--dtype", default="f64", choices=("f64", "f32"), help="arithmetic of the headline run")
     ap.add_argument("--sweeps", type=int, default=1, help="sweeps fused per launch in the headline run")
     ap.add_argument("--fused-sweeps", type=int, default=32, help="extra fused-sweep measurement (0 = skip)")
+    ap.add_argument("--hbm-chains-log2", type=int, default=22, help="chains of the cache-free roofline_hbm run (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length (0 = skip)")
-    ap.add_argument("--extras", type=int, default=1, help="1: also time the float64 build of the headline kernel and "
-                    "BASELINE configs 3-5 (single GPU only; informational, a few seconds)")
+    ap.add_argument("--extras", type=int, default=1, help="1: also time the float32 build of the headline kernel and "
+                    "BASELINE configs 3-5 (informational, a few seconds; configs 3-5 on a single GPU only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -167,9 +239,10 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
-    # CPU baseline first: child processes are started before this process touches the GPU
+    # CPU baseline first, on rank 0 (the other ranks wait at the first barrier): child processes are started before
+    # this process touches the GPU
     cpu = cpu_c = None
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+    if rank == 0 and args.cpu_seconds > 0:
         cpu = cpu_baseline(args.cpu_seconds)
         try:
             cpu_c = cpu_baseline_c(min(args.cpu_seconds, 6.0))
@@ -188,59 +261,115 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     distributed = "RANK" in os.environ           # launched by torch.distributed.run (also at --gpus 1)
+    backend = None
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if rehearsal else "nccl"
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    comm_device = "cpu" if (rehearsal or not distributed) else "cuda"
 
     n_local = 1 << args.chains_log2
-    engine = me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * N_REAL, None, sampling_width=0.05,
-                                 target_acceptance=0.3, temp=1.0, n_chains=n_local, seed=2026, dtype="f32",
-                                 device=local_rank, chain_offset=rank * n_local)
+
+    def make_engine(dtype, chains_log2=args.chains_log2, **extra):
+        n = 1 << chains_log2
+        if chains_log2 > 20:
+            extra.setdefault("cov_mode", "fixed")   # no per-chain covariance fields (4.5 GB at 2^22 x 136 doubles)
+        return me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * N_REAL, None, sampling_width=0.05,
+                                   target_acceptance=0.3, temp=1.0, n_chains=n, seed=2026, dtype=dtype,
+                                   device=local_rank, chain_offset=rank * n, **extra)
+
+    engine = make_engine(args.dtype)
 
     def fence():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(n_launches, sweeps):
-        """(wall seconds, device ms from HIP events on the engine's stream) of n_launches launches."""
+    def timed(eng, n_launches, sweeps):
+        """(wall seconds, device ms from HIP events on the engine's stream) of n_launches launches; max over ranks."""
         fence()
         t0 = time.perf_counter()
-        dev_ms = engine.time_steps(n_launches, sweeps)     # enqueues, records events, waits for the stop event
+        dev_ms = eng.time_steps(n_launches, sweeps)        # enqueues, records events, waits for the stop event
         fence()
         wall = time.perf_counter() - t0
         if distributed:
-            t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=comm_device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall, dev_ms = float(t[0]), float(t[1])
         return wall, dev_ms
 
+    def side_run(eng, chains, per_step_bytes, sweeps, launches):
+        """A side measurement with its own launch count: value, ms per launch, state GB/s."""
+        eng.time_steps(max(20, launches // 5), sweeps)
+        w, d = timed(eng, launches, sweeps)
+        return {"value": float(chains) * world * launches * sweeps / w, "unit": "chain-steps/s", "launches": launches,
+                "sweeps_per_launch": sweeps, "ms_per_launch": d / launches,
+                "effective_state_GBps": per_step_bytes * chains / (d / launches * 1e-3) / 1e9}
+
     if args.warmup > 0:
         engine.time_steps(args.warmup, args.sweeps)
-    wall, dev_ms = timed(args.steps, args.sweeps)
+    wall, dev_ms = timed(engine, args.steps, args.sweeps)
     total_chain_steps = float(n_local) * world * args.steps * args.sweeps
     value = total_chain_steps / wall
     kernel_ms = dev_ms / args.steps                        # average launch duration (events, same timed region)
-    algorithmic = BYTES_PER_CHAIN_STEP * n_local           # bytes one launch must move (state in, state out)
-    achieved = algorithmic / (kernel_ms * 1e-3) / 1e9
+    per_step = BYTES_PER_CHAIN_STEP_F64 if args.dtype == "f64" else BYTES_PER_CHAIN_STEP
+    roofline = roofline_block(args.dtype, args.chains_log2, kernel_ms, bound_label(per_step // 2 * n_local))
+
+    # observability of the multi-GPU layout: how many ranks the collective backend really joined, and who owns what
+    ranks_seen, offsets = 1, [rank * n_local]
+    if distributed:
+        one = torch.ones(1, dtype=torch.float64, device=comm_device)
+        dist.all_reduce(one)
+        ranks_seen = int(round(float(one[0])))
+        gathered = [torch.zeros(1, dtype=torch.int64, device=comm_device) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([rank * n_local], dtype=torch.int64, device=comm_device))
+        offsets = [int(t[0]) for t in gathered]
 
     fused = None
     if args.fused_sweeps > 0:
-        launches = max(4, args.steps // args.fused_sweeps)
-        fwall, fdev = timed(launches, args.fused_sweeps)
-        fused = {"sweeps_per_launch": args.fused_sweeps, "launches": launches,
-                 "value": float(n_local) * world * launches * args.fused_sweeps / fwall, "unit": "chain-steps/s",
-                 "ms_per_launch": fdev / launches,
-                 "effective_state_GBps": algorithmic / (fdev / launches * 1e-3) / 1e9}
-        if args.chains_log2 == 20 and world == 1:
-            fused["valu_issue"] = issue_utilisation(torch, local_rank,
-                                                    float(n_local) * launches * args.fused_sweeps / (fdev * 1e-3))
+        launches = max(40, args.steps // args.fused_sweeps)
+        fused = side_run(engine, n_local, per_step, args.fused_sweeps, launches)
+        fused["dtype"] = args.dtype
 
     stats = pooled_statistics(engine)                      # the one collective: RCCL all-reduce of pooled moments
     engine.sync()
+    del engine
+
+    # the cache-free figure: same kernel, state beyond the 256 MiB Infinity Cache (identity shape, no covariance fields)
+    roofline_hbm = None
+    if args.hbm_chains_log2 > 0 and args.sweeps == 1:
+        big = make_engine(args.dtype, args.hbm_chains_log2, cov_mode="fixed")
+        run = side_run(big, 1 << args.hbm_chains_log2, per_step, 1, SIDE_LAUNCHES)
+        roofline_hbm = roofline_block(args.dtype, args.hbm_chains_log2, run["ms_per_launch"],
+                                      bound_label(per_step // 2 << args.hbm_chains_log2))
+        roofline_hbm["value"] = run["value"]
+        roofline_hbm["launches"] = run["launches"]
+        del big
+
+    # the float32 build of the same kernels (the production dtype): same workload, same protocol
+    f32 = None
+    if args.extras and args.dtype == "f64":
+        e32 = make_engine("f32")
+        run = side_run(e32, n_local, BYTES_PER_CHAIN_STEP, 1, max(args.steps, SIDE_LAUNCHES))
+        f32 = {"value": run["value"], "unit": "chain-steps/s", "ms_per_step": run["ms_per_launch"], "dtype": "f32",
+               "launches": run["launches"],
+               "roofline": roofline_block("f32", args.chains_log2, run["ms_per_launch"],
+                                          bound_label(BYTES_PER_CHAIN_STEP // 2 * n_local))}
+        if args.fused_sweeps > 0:
+            f32["fused"] = side_run(e32, n_local, BYTES_PER_CHAIN_STEP, args.fused_sweeps, 40)
+            if args.chains_log2 == 20 and world == 1:
+                f32["fused"]["valu_issue"] = issue_utilisation(
+                    torch, local_rank, f32["fused"]["value"])
+        if args.hbm_chains_log2 > 0:
+            del e32
+            e32 = make_engine("f32", args.hbm_chains_log2, cov_mode="fixed")
+            run = side_run(e32, 1 << args.hbm_chains_log2, BYTES_PER_CHAIN_STEP, 1, SIDE_LAUNCHES)
+            f32["roofline_hbm"] = roofline_block("f32", args.hbm_chains_log2, run["ms_per_launch"],
+                                                 bound_label(BYTES_PER_CHAIN_STEP // 2 << args.hbm_chains_log2))
+        del e32
 
     extras = None
     if world == 1 and args.extras:
@@ -251,23 +380,23 @@ def main():
             "metric": "MC steps/sec (chains x sweeps) at 2^20 chains, 16 params",
             "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "config 2: 16 real params, isotropic quadratic E=sum x^2, T=1, 2^%d chains per GPU, "
-                                   "identity proposal shape, %d sweep(s) per launch, Philox4x32-10 streams"
-                                   % (args.chains_log2, args.sweeps),
+                                   "identity proposal shape, %d sweep(s) per launch, Philox4x32-10 streams, %s state "
+                                   "and arithmetic%s"
+                                   % (args.chains_log2, args.sweeps, "float64" if args.dtype == "f64" else "float32",
+                                      " (the reference's dtype)" if args.dtype == "f64" else ""),
                        "chains_per_gpu": n_local, "global_chains": n_local * world, "sweeps_per_launch": args.sweeps,
                        "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.chains_log2, args.sweeps),
-                         "kernel": "k_step<float,16,0,EnergyIso,identity>", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": algorithmic,
-                         "note": "144 B per chain-step (fp32 r/w of x[16], energy, width) x 2^%d chains / average "
-                                 "launch duration from HIP events on the engine's stream over the timed region"
-                                 % args.chains_log2},
+            "roofline": roofline,
+            "roofline_hbm": roofline_hbm,
             "cpu_baseline": cpu,
             "cpu_baseline_c": cpu_c,
+            "f32": f32,
             "fused": fused,
             "other_configs": extras,
+            "multi_gpu": {"backend": backend, "ranks_seen_by_allreduce": ranks_seen, "chain_offsets": offsets,
+                          "pooled_chains": stats["n_chains"]},
             "acceptance_rate": stats["acceptance_rate"],
             "pooled_variance_mean": float(sum(stats["covariance"][i][i] for i in range(N_REAL)) / N_REAL),
         }

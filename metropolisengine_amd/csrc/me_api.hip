@@ -194,11 +194,13 @@ int field_info(me_engine *e, int field, void **ptr, int *comps) {
     case ME_FIELD_OBS_MEAN: *ptr = e->obs_mean; *comps = e->nobs; return ME_OK;
     case ME_FIELD_COV:
       if (!e->cov)
-        return fail(e, ME_ERR_UNSUPPORTED, "the per-chain covariance of this parameter space is only kept on request "
-                                           "(me_config.flags: ME_FLAG_TRACK_COVARIANCE)");
+        return fail(e, ME_ERR_UNSUPPORTED, "this engine keeps no per-chain covariance: for large parameter spaces it is "
+                                           "kept on request only (me_config.flags: ME_FLAG_TRACK_COVARIANCE), and not "
+                                           "at all where the field would pass 4 GiB");
       *ptr = e->cov; *comps = e->p; return ME_OK;
     case ME_FIELD_FACTOR:
-      if (!e->factor) return fail(e, ME_ERR_UNSUPPORTED, "per-chain factors are not compiled for these dimensions");
+      if (!e->factor) return fail(e, ME_ERR_UNSUPPORTED, "this engine keeps no per-chain proposal factors (dimensions "
+                                                         "without per-chain kernels, or a field beyond 4 GiB)");
       *ptr = e->factor; *comps = e->p; return ME_OK;
     default: return fail(e, ME_ERR_INVALID, "unknown field id");
   }
@@ -341,12 +343,23 @@ int me_create(const me_config *c, me_engine **out) {
     return fail(nullptr, ME_ERR_UNSUPPORTED,
                 "per-chain adaptive covariance is not compiled for these dimensions; use ME_COV_FIXED or ME_COV_POOLED");
 
+  // The kernels address each field through a buffer descriptor with 32-bit offsets (me_device.h: Field).  The packed
+  // per-chain covariance / factor fields are the widest: where THEY would pass 4 GiB and the proposal shape does not
+  // need them (ME_COV_FIXED / ME_COV_POOLED) the engine simply keeps no per-chain covariance -- as for parameter
+  // spaces without per-chain kernels, the ensemble covariance then comes from me_pooled_moments.
+  bool keep_per_chain = ks->per_chain_cov;
   {
-    // the kernels address each field through a buffer descriptor with 32-bit offsets (me_device.h: Field)
     const long long esz = c->dtype == ME_F32 ? 4 : 8;
-    const long long rows = std::max<long long>(std::max(c->n_real + 2 * c->n_complex, 2 * c->n_real + c->n_complex),
-                                               ks->per_chain_cov ? packed_total(c->n_real, c->n_complex) : 0);
-    if (rows * c->n_chains * esz >= (1ll << 32))
+    const long long limit = 1ll << 32;
+    if (keep_per_chain && (long long)packed_total(c->n_real, c->n_complex) * c->n_chains * esz >= limit) {
+      if (c->cov_mode == ME_COV_REFERENCE)
+        return fail(nullptr, ME_ERR_UNSUPPORTED,
+                    "the per-chain covariance field would exceed 4 GiB on this engine; shard the chains over more "
+                    "engines or use ME_COV_FIXED / ME_COV_POOLED");
+      keep_per_chain = false;
+    }
+    const long long rows = std::max<long long>(c->n_real + 2 * c->n_complex, 2 * c->n_real + c->n_complex);
+    if (rows * c->n_chains * esz >= limit)
       return fail(nullptr, ME_ERR_UNSUPPORTED,
                   "a per-chain field would exceed 4 GiB on this engine; shard the chains over more engines");
   }
@@ -403,9 +416,9 @@ int me_create(const me_config *c, me_engine **out) {
   ME_CREATE_HIP(hipMalloc(&e->width, n * e->width_rows * es));
   ME_CREATE_HIP(hipMalloc(&e->mean, n * e->d * es));
   ME_CREATE_HIP(hipMalloc(&e->obs_mean, n * e->nobs * es));
-  if (ks->per_chain_cov || (ks->tracks_cov && (c->flags & ME_FLAG_TRACK_COVARIANCE)))
+  if (keep_per_chain || (!ks->per_chain_cov && ks->tracks_cov && (c->flags & ME_FLAG_TRACK_COVARIANCE)))
     ME_CREATE_HIP(hipMalloc(&e->cov, n * e->p * es));
-  if (ks->per_chain_cov) ME_CREATE_HIP(hipMalloc(&e->factor, n * e->p * es));
+  if (keep_per_chain) ME_CREATE_HIP(hipMalloc(&e->factor, n * e->p * es));
   ME_CREATE_HIP(hipMalloc(&e->shared_factor, (size_t)e->p * es));
   if (e->nc == 0) ME_CREATE_HIP(hipMalloc(&e->shared_full, (size_t)e->nr * e->nr * es));
   if (e->shared_full && ks->prepare_matrix) ME_CREATE_HIP(hipMalloc(&e->shared_image, ks->matrix_image_bytes));

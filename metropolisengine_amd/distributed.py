@@ -76,7 +76,18 @@ def pooled_statistics(engine, group=None):
     nr, nc = engine.num_real_params, engine.num_complex_params
     size = moments_size(nr, nc)
     if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl":
-        buf = torch.empty(size, dtype=torch.float64, device="cuda")
+        # The buffer must live on the ENGINE's GPU (the engine's own stream writes it) and that must be the device the
+        # process group communicates from: a mismatch would be a cross-device write, not an error message.
+        dev = torch.device("cuda", engine.device)
+        if torch.cuda.current_device() != engine.device:
+            raise RuntimeError("pooled_statistics: torch's current device is cuda:%d but the engine lives on cuda:%d; "
+                               "call torch.cuda.set_device(engine.device) (one process per GPU)"
+                               % (torch.cuda.current_device(), engine.device))
+        buf = torch.empty(size, dtype=torch.float64, device=dev)
+        # the caching allocator may hand back a block an earlier torch kernel is still using on torch's stream; the
+        # engine writes from its own stream, so order the two explicitly (me_pooled_moments_device synchronises the
+        # engine's stream before it returns, which orders the all-reduce behind the write)
+        torch.cuda.current_stream(dev).synchronize()
         engine.pooled_moments_into(buf.data_ptr(), size)          # k_pool_reduce straight into the RCCL buffer
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         total = buf.cpu().numpy()
