@@ -1,0 +1,296 @@
+// k_step for the dense quadratic-form energy E = x^T A x on 64 real parameters in FLOAT64 -- BASELINE config 4 at
+// the reference's precision -- with the quadratic form, and for a shared (pooled) proposal factor the proposal L g,
+// on the matrix cores (v_mfma_f64_16x16x4_f64).
+//
+// Reference semantics are those of k_step (me_device.h): step_real_group, metropolis_engine.py:225-239 with the user
+// energy at :231 being x^T A x, proposals x' = x + sigma L g (:261-272).  Only the evaluation strategy differs.
+//
+// What the matrix instruction is for here.  MEASURED on MI355X (tools/dev/mfma_f64_probe.hip): one
+// v_mfma_f64_16x16x4_f64 (2 048 flop) issues every ~64-79 cycles per SIMD, i.e. exactly the v_fma_f64 rate
+// (64 lanes x 2 flop per 4 cycles), and an MFMA-only loop, a float64-VALU loop and their interleave take
+// 1.23 / 0.60 / 1.77 ms -- the times ADD, in one wave and across two waves of a SIMD.  So it buys no flops and no
+// overlap with the Philox / Box-Muller work; it buys DENSITY: the generic k_step<double,64,0,EnergyDense> needs 4 096
+// v_fma_f64 with 4 096 scalar-loaded coefficients per chain-step and 256 live registers of state beside them, and
+// compiled to 32-49 KB of scratch per lane (16 ms per launch).  Here 160 instructions and 32 accumulator registers do
+// the product, the coefficients are 40 LDS words per lane, and nothing spills.
+//
+//   * Only the symmetric part of A matters to x^T A x.  T = tril(A + A^T, -1) + diag(A) is LOWER TRIANGULAR and
+//     E = x'^T (T x'), so row block mb (16 rows) of the product needs k < 16 (mb + 1) only: 4+8+12+16 = 40 k-steps of
+//     4 instead of 64, times 4 chain blocks = 160 MFMAs instead of 256.  The shared factor L is lower triangular by
+//     construction and goes through the same code (fold(L) = L).
+//   * One wavefront = one tile of 64 chains, chain = lane for the state x[64] (128 VGPRs).  The proposals are parked
+//     in LDS as xp[row][chain] (32 KiB per wave, chain index XOR-swizzled by the row's parity so that both the
+//     MFMA B-operand reads -- lane l wants row 4 ks + (l >> 4), chain 16 nb + (l & 15) -- and the owners' column
+//     accesses are bank-conflict free).
+//   * A-operand fragments of T: image[(mb, ks)][lane] = T[16 mb + (l & 15)][4 ks + (l >> 4)], built once per engine
+//     (k_dense64_f64_fragments), 20 KiB, copied to LDS once per block.  The factor image (CK_SHARED) stays in global
+//     memory (L1/L2 resident): LDS is full.
+//   * Results: lane l holds rows (l >> 4) + 4 r (r < 4) of chain 16 nb + (l & 15) of a 16 x 16 block (the float64 C/D
+//     map differs from every other MFMA's, checked in the probe).  The energy is reduced where the results are:
+//     partial dot products against xp from LDS, then a 4 x 4 exchange through 2 KiB of LDS brings each chain's
+//     total home.  For L g the row blocks are produced in DESCENDING order, so that block mb of the result can
+//     overwrite rows 16 mb .. 16 mb + 15 of g in place (later blocks read only lower rows).
+//   * One wave per SIMD (LDS-bound: 4 x 34 KiB + 20 KiB of the CU's 160), 512 registers each: the NEXT tile's 66 rows
+//     are loaded into a second register set while the current tile computes, so HBM latency is off the critical
+//     path; a tile costs ~24k cycles of arithmetic against ~66 KiB of traffic, which makes the kernel roughly
+//     balanced between the float64 pipe and HBM.
+#pragma once
+
+#include "me_device.h"
+#include "me_per_device.h"
+
+namespace me {
+
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+#ifndef ME_DENSE64_F64_RNG_UNROLL
+#define ME_DENSE64_F64_RNG_UNROLL 2     // 2 blocks (4 Box-Muller pairs) per iteration: -2.5 % on the fused sweep against 1; 4: no further gain
+#endif
+constexpr int kDense64F64Threads = 256;                  // 4 waves, one per SIMD
+constexpr int kDense64F64Frags = 40;                     // (mb, ks) pairs with 4 ks < 16 (mb + 1)
+constexpr int kDense64F64ImageDoubles = kDense64F64Frags * 64;
+constexpr int kDense64F64WaveDoubles = 64 * 64 + 256;    // xp[64][64] + the 4 x 4 x 16 energy exchange
+constexpr size_t kDense64F64LdsBytes = sizeof(double) * (kDense64F64ImageDoubles + 4 * kDense64F64WaveDoubles);
+
+__host__ __device__ constexpr int dense64_f64_frag_index(int mb, int ks) { return 2 * mb * (mb + 1) + ks; }
+
+// image[(mb, ks)][lane] = T[16 mb + (lane & 15)][4 ks + (lane >> 4)],  T = tril(M + M^T, -1) + diag(M)
+template <int UNUSED = 0>   // a template so that every kernel-set object may carry it (one definition after linking)
+__global__ void k_dense64_f64_fragments(const double *__restrict__ m, double *__restrict__ image) {
+  for (int idx = threadIdx.x; idx < kDense64F64ImageDoubles; idx += blockDim.x) {
+    const int frag = idx >> 6, lane = idx & 63;
+    int mb = 0;
+    while (dense64_f64_frag_index(mb + 1, 0) <= frag) ++mb;
+    const int ks = frag - dense64_f64_frag_index(mb, 0);
+    const int i = 16 * mb + (lane & 15), j = 4 * ks + (lane >> 4);
+    image[idx] = i > j ? m[i * 64 + j] + m[j * 64 + i] : (i == j ? m[i * 64 + i] : 0.0);
+  }
+}
+
+// swizzled position of (row, chain) in a wave's xp block
+__device__ __forceinline__ int xp_at(int row, int chain) { return row * 64 + (chain ^ ((row & 1) << 4)); }
+
+// Y = T X for the wave's 64 columns parked in `xp`; row blocks in the order mb = first, first + dir, ...; after each row
+// block `sink(mb, acc)` receives its four 16 x 16 result blocks (acc[nb][r]: row 16 mb + (lane >> 4) + 4 r of chain
+// 16 nb + (lane & 15)).  FRAG_LDS: fragments from LDS (conflict-free lane-linear reads), else from global memory.
+template <bool DESCENDING, class Sink>
+__device__ __forceinline__ void wave_tri_product_64(const double *__restrict__ frags, const double *xp, int lane, Sink &&sink) {
+  const int j = lane & 15, h = lane >> 4;
+#pragma unroll
+  for (int step = 0; step < 4; ++step) {
+    const int mb = DESCENDING ? 3 - step : step;
+    f64x4 acc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) acc[nb] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4 * (mb + 1); ++ks) {
+      const double a = frags[(dense64_f64_frag_index(mb, ks) << 6) + lane];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const double b = xp[xp_at(4 * ks + h, 16 * nb + j)];
+        acc[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[nb], 0, 0, 0);
+      }
+    }
+    sink(mb, acc);
+    // one row block at a time: without this fence hipcc merges the four row blocks to share their B reads, which keeps
+    // all sixteen accumulators (128 registers) live and spills a row of the prefetched tile -- and one spilled row
+    // means an s_waitcnt vmcnt(0) right behind the prefetch, i.e. no prefetch at all
+    asm volatile("" ::: "memory");
+  }
+}
+
+template <int CK>
+__global__ void __launch_bounds__(kDense64F64Threads, 1)
+    k_step_dense64_f64(StepArgs<double> a, const double *__restrict__ t_image, const double *__restrict__ l_image) {
+  constexpr int D = 64;
+  using N_ = Num<double>;
+  extern __shared__ __attribute__((aligned(16))) double smem64[];
+  double *lds_t = smem64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double *xp = smem64 + kDense64F64ImageDoubles + wave * kDense64F64WaveDoubles;
+  double *exch = xp + 64 * 64;
+  for (int idx = threadIdx.x; idx < kDense64F64ImageDoubles; idx += kDense64F64Threads) lds_t[idx] = t_image[idx];
+  N_::prepare();    // the log table of the float64 Box-Muller; ends with the block barrier that also covers lds_t
+
+  const int j = lane & 15, h = lane >> 4;
+  unsigned int wave_accepted = 0;
+  bool bad_energy = false, bad_width = false;
+  const Field<double> fx(a.x, a.n, D), fe(a.energy, a.n, 1), fw(a.width, a.n, 1);
+  const long long n_tiles = (a.n + 63) / 64;
+  const long long tile_stride = (long long)gridDim.x * (kDense64F64Threads / 64);
+
+  // every lane stays active (the MFMAs need the whole wavefront): tail lanes shadow the last chain
+  auto chain_of = [&](long long tile) {
+    const long long c_raw = tile * 64 + lane;
+    return c_raw < a.n ? c_raw : a.n - 1;
+  };
+  long long tile = (long long)blockIdx.x * (kDense64F64Threads / 64) + wave;
+  double x[D], e = 0.0, w = 0.0;
+  if (tile < n_tiles) {
+    const unsigned int coff = (unsigned int)chain_of(tile) * 8u;
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = fx.load(d, coff);
+    e = fe.load(0, coff);
+    w = fw.load(0, coff);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);        // same reason as at the end of the tile loop: enter it with nothing pending
+  while (tile < n_tiles) {
+    const long long c = chain_of(tile);
+    const bool live = tile * 64 + lane < a.n;
+    const unsigned int coff = (unsigned int)c * 8u;
+    const unsigned long long gid = a.chain_offset + (unsigned long long)c;
+    // the next tile's rows travel while this one computes (second register set; one wave per SIMD has 512 registers)
+    const long long next = tile + tile_stride;
+    const bool have_next = next < n_tiles;
+    double xn[D], en = 0.0, wn = 0.0;
+    // The row offsets (row x n x 8 bytes, scalar operands of the buffer loads / stores) are loop-invariant: left alone,
+    // hipcc keeps all 64 of them live across the whole tile loop, runs out of SGPRs and spills them to VGPR lanes it
+    // no longer has (the prefetch then went through scratch, one row at a time).  An opaque copy per tile makes them
+    // cheap scalar arithmetic next to each access instead.
+    Field<double> fxt = fx;
+    asm volatile("" : "+s"(fxt.row_bytes));
+    auto prefetch = [&]() {
+      if (have_next) {       // wave-uniform
+        const unsigned int noff = (unsigned int)chain_of(next) * 8u;
+#pragma unroll
+        for (int d = 0; d < D; ++d) xn[d] = fxt.load(d, noff);
+        en = fe.load(0, noff);
+        wn = fw.load(0, noff);
+      }
+    };
+    // WHEN it is issued matters: a wave can have at most 63 vector-memory operations outstanding (vmcnt is 6 bits), so
+    // the 66 loads queued directly behind the previous tile's 66 stores stalled the wave at issue until most of both had
+    // completed (one-sweep launches took the arithmetic PLUS ~66 us).  The loads therefore go out after the first
+    // sweep's draws (the stores have drained by then) and have the matrix phase to arrive.  With a shared factor they
+    // also have to stay behind that sweep's L g, whose fragment loads from global memory would otherwise queue behind
+    // them (loads return in order).
+
+    for (int s = 0; s < a.n_sweeps; ++s) {
+      const unsigned long long step = a.step_index + (unsigned long long)s;
+      // the fragment reads of T are loop-invariant too (80 registers if hoisted out of the sweep loop): keep them here
+      asm volatile("" ::: "memory");
+      // ---- 64 normals (Philox blocks 0..15, two Box-Muller pairs each) -> LDS.  A ROLLED loop: unrolled, hipcc
+      // interleaves the sixteen blocks for ILP and their live values push rows of the prefetched tile into scratch.
+#pragma unroll ME_DENSE64_F64_RNG_UNROLL
+      for (int b = 0; b < 16; ++b) {
+        U4 ctr;
+        ctr.x = (uint32_t)gid;
+        ctr.y = (uint32_t)(gid >> 32);
+        ctr.z = (uint32_t)step;
+        ctr.w = ((uint32_t)(step >> 32) << 16) | (uint32_t)b;
+        const U4 o = philox4x32_10(ctr, a.seed_lo, a.seed_hi);
+        double g[4];
+        N_::normal_pair(o.x, o.y, g[0], g[1]);
+        N_::normal_pair(o.z, o.w, g[2], g[3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xp[xp_at(4 * b + i, lane)] = g[i];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if constexpr (CK == CK_SHARED) {
+        // y = L g, row blocks descending, written over g in place
+        wave_tri_product_64<true>(l_image, xp, lane, [&](int mb, const f64x4 (&acc)[4]) {
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xp[xp_at(16 * mb + h + 4 * r, 16 * nb + j)] = acc[nb][r];
+          __builtin_amdgcn_wave_barrier();
+        });
+      }
+      if (s == 0) prefetch();
+      // x' = x + w g (or x + w L g) by the owners, in place
+#pragma unroll
+      for (int d = 0; d < D; ++d) xp[xp_at(d, lane)] = x[d] + w * xp[xp_at(d, lane)];
+      __builtin_amdgcn_wave_barrier();
+      // ---- E' = x'^T (T x'): partial dot products where the results are, then the 4 x 4 exchange
+      double part[4] = {0.0, 0.0, 0.0, 0.0};
+      wave_tri_product_64<false>(lds_t, xp, lane, [&](int mb, const f64x4 (&acc)[4]) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part[nb] = __builtin_fma(xp[xp_at(16 * mb + h + 4 * r, 16 * nb + j)], acc[nb][r], part[nb]);
+      });
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) exch[(nb * 4 + h) * 16 + j] = part[nb];
+      __builtin_amdgcn_wave_barrier();
+      double e_new = 0.0;
+#pragma unroll
+      for (int hh = 0; hh < 4; ++hh) e_new += exch[((lane >> 4) * 4 + hh) * 16 + (lane & 15)];
+      // ---- accept uniform: word 64 = block 16, output 0
+      U4 ctr;
+      ctr.x = (uint32_t)gid;
+      ctr.y = (uint32_t)(gid >> 32);
+      ctr.z = (uint32_t)step;
+      ctr.w = ((uint32_t)(step >> 32) << 16) | 16u;
+      const double u = N_::unit(philox4x32_10(ctr, a.seed_lo, a.seed_hi).x);
+      bool rejected = false;
+      if (a.reject_kind == ME_REJECT_ABS_REAL0_GE) rejected = !(N_::abs_(xp[xp_at(0, lane)]) < a.reject_bound);
+      const double diff = e_new - e;
+      bool accept = diff <= 0.0;
+      if (a.temp > 0.0) accept = accept || N_::uphill(u, diff, a.inv_temp, a.inv_temp_log2e);
+      accept = accept && !rejected;
+      bad_energy |= (live && !rejected && !N_::finite(e_new));
+      if (accept) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) x[d] = xp[xp_at(d, lane)];
+      }
+      e = accept ? e_new : e;
+      w = N_::adapt(w, accept, a.ratio, a.p, a.damping, a.up, a.down);
+      wave_accepted += (unsigned int)__popcll(__ballot(accept && live));
+      __builtin_amdgcn_wave_barrier();      // the next sweep overwrites xp
+    }
+    bad_width |= live && !(w > 0.0);
+    // vmcnt is a 6-bit counter and memory operations retire in order: once this tile's 66 stores and the next
+    // prefetch's 66 loads are queued behind them, ANY wait on the rows prefetched above can only be expressed as
+    // "drain (almost) everything".  Wait for them here instead -- they were issued a whole tile of arithmetic ago, so
+    // this costs nothing -- and nothing later in the loop has to wait on the vector-memory queue at all.
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
+    if (live) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) fxt.store(d, coff, x[d]);
+      fe.store(0, coff, e);
+      fw.store(0, coff, w);
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = xn[d];
+    e = en;
+    w = wn;
+    tile = next;
+  }
+  if (lane == 0 && wave_accepted) {
+    unsigned long long *slot = a.accept_slots + (size_t)blockIdx.x * (kDense64F64Threads / 64) + wave;
+    *slot += (unsigned long long)wave_accepted;
+  }
+  const unsigned int bits = (bad_energy ? ST_NONFINITE_ENERGY : 0u) | (bad_width ? ST_BAD_WIDTH : 0u);
+  if (bits) atomicOr(a.status, bits);
+}
+
+// Host launcher: one persistent 256-thread workgroup per CU (LDS admits no more).  Both per-device properties -- the
+// raised dynamic-LDS limit and the CU count -- are resolved per device of the process (me_per_device.h).
+template <int CK>
+inline hipError_t launch_step_dense64_f64(const StepArgs<double> &a, const double *t_image, const double *l_image,
+                                          int grid_blocks, hipStream_t stream) {
+  static PerDevice<hipError_t> attr_cache;
+  static PerDevice<int> cu_cache;
+  int device = 0;
+  hipError_t rc = hipGetDevice(&device);
+  if (rc != hipSuccess) return rc;
+  rc = attr_cache.get(device, [] {
+    return hipFuncSetAttribute((const void *)k_step_dense64_f64<CK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)kDense64F64LdsBytes);
+  });
+  if (rc != hipSuccess) return rc;
+  const int cus = cu_cache.get(device, [device] {
+    int count = 0;
+    if (hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || count <= 0) return 256;
+    return count;
+  });
+  long long blocks = (a.n + kDense64F64Threads - 1) / kDense64F64Threads;
+  const long long cap = grid_blocks > 0 ? grid_blocks : (long long)cus;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL((k_step_dense64_f64<CK>), dim3((unsigned)blocks), dim3(kDense64F64Threads), kDense64F64LdsBytes, stream,
+                     a, t_image, l_image);
+  return hipGetLastError();
+}
+
+}  // namespace me

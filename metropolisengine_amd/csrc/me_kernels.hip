@@ -7,6 +7,7 @@
 #include "me_device.h"
 #include "me_dense_mfma.h"
 #include "me_dense_bf16x3.h"
+#include "me_dense_f64.h"
 #include "me_pool_gram.h"
 #include "me_magphase.h"
 
@@ -205,6 +206,16 @@ hipError_t step_with(const StepLaunch &l, const Energy &en, hipStream_t stream) 
       return launch_step_dense64_bf16x3<CK_SHARED>(a, (const unsigned int *)l.energy_image,
                                                    (const unsigned int *)l.factor_image, l.grid_blocks, stream);
     return hipErrorInvalidValue;
+  } else if constexpr (std::is_same<R, double>::value && NR == 64 && NC == 0 &&
+                       std::is_same<Energy, EnergyDense<double, 64, 0>>::value) {
+    // ... and at the reference's precision: v_mfma_f64_16x16x4_f64 on the folded lower triangle (me_dense_f64.h)
+    if (!l.energy_image) return hipErrorInvalidValue;
+    if (l.cov_kind == CK_IDENTITY)
+      return launch_step_dense64_f64<CK_IDENTITY>(a, (const double *)l.energy_image, nullptr, l.grid_blocks, stream);
+    if (l.cov_kind == CK_SHARED && l.factor_image)
+      return launch_step_dense64_f64<CK_SHARED>(a, (const double *)l.energy_image, (const double *)l.factor_image,
+                                                l.grid_blocks, stream);
+    return hipErrorInvalidValue;
   } else
 #endif
     return launch_step_group<R, Energy, false>(l, a, en, grid, block, stream);
@@ -374,15 +385,25 @@ hipError_t prepare_matrix_f32(const void *factor_full, void *image, hipStream_t 
 }
 constexpr size_t kMatrixImageBytes = (NR == 64 && NC == 0) ? sizeof(unsigned int) * kBf16FragWords : 0;
 #define ME_PREPARE_MATRIX_F32 kMatrixImageBytes, (kMatrixImageBytes ? prepare_matrix_f32 : nullptr), pool_stage1_f32()
+hipError_t prepare_matrix_f64(const void *matrix, void *image, hipStream_t stream) {
+  if constexpr (NR == 64 && NC == 0) {
+    hipLaunchKernelGGL(k_dense64_f64_fragments<0>, dim3(1), dim3(256), 0, stream, (const double *)matrix, (double *)image);
+    return hipGetLastError();
+  }
+  return hipSuccess;
+}
+constexpr size_t kMatrixImageBytesF64 = (NR == 64 && NC == 0) ? sizeof(double) * kDense64F64ImageDoubles : 0;
+#define ME_PREPARE_MATRIX_F64 kMatrixImageBytesF64, (kMatrixImageBytesF64 ? prepare_matrix_f64 : nullptr), nullptr
 #else
 #define ME_PREPARE_MATRIX_F32 0, nullptr, pool_stage1_f32()
+#define ME_PREPARE_MATRIX_F64 0, nullptr, nullptr
 #endif
 const KernelSet kSetF32 = {ME_SET_NAME, ME_F32, NR, NC, ME_PER_CHAIN != 0, (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0), has_energy, energy_terms, step<float>,
                            (NC > 0 && ME_PER_CHAIN) ? magphase<float> : nullptr, measure<float>, init_energy<float>,
                            ME_PREPARE_MATRIX_F32};
 const KernelSet kSetF64 = {ME_SET_NAME, ME_F64, NR, NC, ME_PER_CHAIN != 0, (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0), has_energy, energy_terms, step<double>,
                            (NC > 0 && ME_PER_CHAIN) ? magphase<double> : nullptr, measure<double>, init_energy<double>,
-                           0, nullptr, nullptr};
+                           ME_PREPARE_MATRIX_F64};
 
 struct Registrar {
   Registrar() {
