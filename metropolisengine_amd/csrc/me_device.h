@@ -120,6 +120,9 @@ struct Num<double> {
 // scalar register (soffset = row * n * sizeof(R)) and the chain offset in ONE vector register, so a kernel that
 // touches dozens of rows holds no per-row 64-bit addresses (they cost 2 VGPRs each and were being spilled).
 // Out-of-range accesses are dropped by the hardware range check.  me_create guarantees rows*n*sizeof(R) < 4 GiB.
+#ifndef ME_NT_AUX
+#define ME_NT_AUX 2      // experiments: 0 = default cache policy for the packed fields too
+#endif
 template <typename R>
 struct Field {
   __amdgpu_buffer_rsrc_t rsrc;
@@ -137,6 +140,29 @@ struct Field {
       return __builtin_bit_cast(R, v);
     }
   }
+  // Non-temporal forms (cache-policy bit 1 of the buffer instruction, "nt") for the packed per-chain covariance /
+  // factor fields: 0.5-2.3 GB that a launch touches exactly once.  Streamed with the default policy they push the
+  // chain state (72-150 MB, otherwise resident in the 256 MiB Infinity Cache from launch to launch) out to HBM:
+  // tools/dev/rows_probe3.hip, the pattern of k_step with per-chain factors at 16 parameters: 151.7 us default,
+  // 118.4 us with nt on the factor rows (memory only, no arithmetic).
+  __device__ __forceinline__ R load_nt(int row, unsigned int chain_off) const {
+    if constexpr (sizeof(R) == 4) {
+      return __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b32(rsrc, chain_off, (unsigned int)row * row_bytes, ME_NT_AUX));
+    } else {
+      const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, chain_off, (unsigned int)row * row_bytes, ME_NT_AUX);
+      return __builtin_bit_cast(R, v);
+    }
+  }
+  __device__ __forceinline__ void store_nt(int row, unsigned int chain_off, R value) const {
+    if constexpr (sizeof(R) == 4) {
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, value), rsrc, chain_off,
+                                            (unsigned int)row * row_bytes, ME_NT_AUX);
+    } else {
+      using v2 = decltype(__builtin_amdgcn_raw_buffer_load_b64(rsrc, 0u, 0u, 0));
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2, value), rsrc, chain_off,
+                                            (unsigned int)row * row_bytes, ME_NT_AUX);
+    }
+  }
   __device__ __forceinline__ void store(int row, unsigned int chain_off, R value) const {
     if constexpr (sizeof(R) == 4) {
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, value), rsrc, chain_off,
@@ -148,6 +174,19 @@ struct Field {
     }
   }
 };
+
+// accesses of k_measure / k_factor to the packed covariance and factor fields; NT: streamed once per launch from / to
+// HBM (the launcher decides by working-set size, me_kernels.hip)
+template <bool NT, typename R>
+__device__ __forceinline__ R packed_load(const Field<R> &f, int row, unsigned int chain_off) {
+  if constexpr (NT) return f.load_nt(row, chain_off);
+  else return f.load(row, chain_off);
+}
+template <bool NT, typename R>
+__device__ __forceinline__ void packed_store(const Field<R> &f, int row, unsigned int chain_off, R value) {
+  if constexpr (NT) f.store_nt(row, chain_off, value);
+  else f.store(row, chain_off, value);
+}
 
 // packed sizes up to this are kept in registers by the per-chain factor kernels (build.py: MAX_PACKED_IN_REGISTERS)
 constexpr int kMaxPackedInRegisters = 160;
@@ -398,7 +437,8 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   const long long stride = (long long)gridDim.x * blockDim.x;   // 64 threads per block, or 256 for fused sweeps
   using Ledger = EnergyLedger<R, Energy, GROUP>;
   const Field<R> fx(a.x, a.n, D), fe(a.energy, a.n, Ledger::T), fw(a.width, a.n, MIXED ? 3 : 1);
-  const Field<R> ffac(a.factor, a.n, CK == CK_PER_CHAIN ? NR * (NR + 1) / 2 + NC * NC : 0);
+  constexpr bool PER_CHAIN = CK == CK_PER_CHAIN || CK == CK_PER_CHAIN_NT;
+  const Field<R> ffac(a.factor, a.n, PER_CHAIN ? NR * (NR + 1) / 2 + NC * NC : 0);
   for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
     R x[D];
@@ -416,9 +456,15 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
       }
     }
     const unsigned long long gid = a.chain_offset + (unsigned long long)c;
-    // CK_PER_CHAIN reads element k at factor[k*n + c] (coalesced); CK_SHARED reads factor[k] (wave-uniform)
+    // CK_PER_CHAIN(_NT) reads element k at factor[k*n + c] (coalesced; hipcc hoists all of them out of the sweep loop, so
+    // the factor is read once per launch); CK_SHARED reads factor[k] (wave-uniform scalar loads).  The _NT variant reads
+    // non-temporally: chosen by the launcher when the working set cannot stay in the Infinity Cache (me_kernels.hip).
+    // Tried and dropped: handing the entries out of two alternating register batches (106 instead of 221 VGPRs, four
+    // wavefronts per SIMD instead of two) changed nothing -- this kernel sits on the memory-only floor of its access
+    // pattern at either occupancy (tools/dev/rows_probe3.hip).
     auto fac = [&](int k) -> R {
-      if constexpr (CK == CK_PER_CHAIN) return ffac.load(k, coff);
+      if constexpr (CK == CK_PER_CHAIN_NT) return ffac.load_nt(k, coff);
+      else if constexpr (CK == CK_PER_CHAIN) return ffac.load(k, coff);
       else return a.factor[k];
     };
 
@@ -649,8 +695,11 @@ __device__ __forceinline__ void cholesky_packed(R (&m)[NR * (NR + 1) / 2 + NC * 
 // loads of every phase batched ahead of its stores this is the faster form for every per-chain kernel set, 16 real
 // parameters (136 entries, 253 VGPRs, two wavefronts per SIMD) included: 460 us against 570 us for the split form
 // (FUSED = false followed by k_factor), which is kept for experiments (-DME_MEASURE_FUSED_MAX_P).
-template <typename R, int NR, int NC, bool PER_CHAIN_COV, bool FUSED>
-__global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
+#ifndef ME_MEASURE_WAVES
+#define ME_MEASURE_WAVES 1
+#endif
+template <typename R, int NR, int NC, bool PER_CHAIN_COV, bool FUSED, bool NT>
+__global__ void __launch_bounds__(kStepThreads, ME_MEASURE_WAVES) k_measure(MeasureArgs<R> a) {
   constexpr int D = NR + 2 * NC;
   constexpr int PR = NR * (NR + 1) / 2;
   constexpr int P = PR + NC * NC;
@@ -774,7 +823,7 @@ __global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
         // the packed matrix is read whole, then updated and written back (FUSED keeps it for the Cholesky anyway)
         R m[P];
 #pragma unroll
-        for (int k = 0; k < P; ++k) m[k] = fcov.load(k, coff);
+        for (int k = 0; k < P; ++k) m[k] = packed_load<NT>(fcov, k, coff);
 #pragma unroll
         for (int i = 0; i < NR; ++i)
 #pragma unroll
@@ -782,7 +831,7 @@ __global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
             const int k = tri(i, j);
             R v = m[k] * a.cov_keep + delta[i] * delta[j] * a.inv_i;
             if (i == j) v += eps;
-            fcov.store(k, coff, v);
+            packed_store<NT>(fcov, k, coff, v);
             m[k] = v;
           }
 #pragma unroll
@@ -794,21 +843,21 @@ __global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
             const int kr = cre(PR, i, j), ki = cim(PR, i, j);
             const R vr = m[kr] * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
             const R vi = m[ki] * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
-            fcov.store(kr, coff, vr);
-            fcov.store(ki, coff, vi);
+            packed_store<NT>(fcov, kr, coff, vr);
+            packed_store<NT>(fcov, ki, coff, vi);
             m[kr] = vr;
             m[ki] = -vi;   // the proposals use conj(K) (quirk Q3, :292-298)
           }
           const int kd = cdiag(PR, i);
           const R vd = m[kd] * a.cov_keep + (ai * ai + bi * bi) * a.inv_i + eps_c;
-          fcov.store(kd, coff, vd);
+          packed_store<NT>(fcov, kd, coff, vd);
           m[kd] = vd;
         }
         if constexpr (FUSED) {
           if (a.write_factor) {
             cholesky_packed<R, NR, NC>(m, bad_pivot);
 #pragma unroll
-            for (int k = 0; k < P; ++k) ffac.store(k, coff, m[k]);
+            for (int k = 0; k < P; ++k) packed_store<NT>(ffac, k, coff, m[k]);
           }
         }
         }   // !STREAM
@@ -819,7 +868,7 @@ __global__ void __launch_bounds__(kStepThreads) k_measure(MeasureArgs<R> a) {
 }
 
 // Refresh the per-chain proposal factors from the per-chain covariance: factor = chol(C_r), chol(conj(K)).
-template <typename R, int NR, int NC>
+template <typename R, int NR, int NC, bool NT>
 __global__ void __launch_bounds__(kStepThreads) k_factor(const R *cov, R *factor, unsigned int *status, long long n) {
   constexpr int PR = NR * (NR + 1) / 2;
   constexpr int P = PR + NC * NC;
@@ -830,14 +879,14 @@ __global__ void __launch_bounds__(kStepThreads) k_factor(const R *cov, R *factor
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
     R m[P];
 #pragma unroll
-    for (int k = 0; k < P; ++k) m[k] = fcov.load(k, coff);
+    for (int k = 0; k < P; ++k) m[k] = packed_load<NT>(fcov, k, coff);
 #pragma unroll
     for (int i = 0; i < NC; ++i)
 #pragma unroll
       for (int j = 0; j < i; ++j) m[cim(PR, i, j)] = -m[cim(PR, i, j)];   // conj(K) (quirk Q3, :292-298)
     cholesky_packed<R, NR, NC>(m, bad_pivot);
 #pragma unroll
-    for (int k = 0; k < P; ++k) ffac.store(k, coff, m[k]);
+    for (int k = 0; k < P; ++k) packed_store<NT>(ffac, k, coff, m[k]);
   }
   if (bad_pivot) atomicOr(status, (unsigned int)ST_BAD_PIVOT);
 }

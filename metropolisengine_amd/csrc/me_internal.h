@@ -11,7 +11,9 @@
 namespace me {
 
 // How the step kernel obtains the proposal shape.
-enum CovKind { CK_IDENTITY = 0, CK_SHARED = 1, CK_PER_CHAIN = 2 };
+// CK_PER_CHAIN_NT is a kernel variant, not an engine state: the per-chain factor is read non-temporally (working sets
+// beyond the Infinity Cache, me_kernels.hip: launch_step_cov).
+enum CovKind { CK_IDENTITY = 0, CK_SHARED = 1, CK_PER_CHAIN = 2, CK_PER_CHAIN_NT = 3 };
 
 // which coordinates a step launch moves (row index of the adapting width in mixed engines)
 enum StepGroup { GROUP_ALL = 0, GROUP_REAL = 1, GROUP_COMPLEX = 2 };
@@ -21,6 +23,10 @@ enum StatusBits : uint32_t {
   ST_BAD_PIVOT = 2u,         // Cholesky pivot <= 0 while refreshing a proposal factor
   ST_BAD_WIDTH = 4u          // sampling width <= 0 or non-finite (metropolis_engine.py:438)
 };
+
+// A kernel whose per-launch working set stays below this is served from the 256 MiB Infinity Cache from launch to
+// launch (measured: 151 MB and 226 MB sets stay resident, MI355X_MICROARCH.md); larger ones stream from HBM.
+constexpr long long kInfinityCacheBudget = 224ll << 20;
 
 constexpr int kBlockThreads = 256;  // block size of the dimension-independent kernels (me_generic.hip)
 // Block size of the per-chain kernels (k_step, k_measure, ...): one lane owns one chain.  Measured on MI355X at

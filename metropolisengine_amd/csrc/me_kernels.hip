@@ -159,7 +159,21 @@ hipError_t launch_step_cov(const StepLaunch &l, const StepArgs<R> &a, const Ener
     case CK_IDENTITY: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_IDENTITY, INJECT, GROUP>), grid, block, 0, stream, a, en); break;
     case CK_SHARED: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_SHARED, INJECT, GROUP>), grid, block, 0, stream, a, en); break;
 #if ME_PER_CHAIN
-    case CK_PER_CHAIN: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_PER_CHAIN, INJECT, GROUP>), grid, block, 0, stream, a, en); break;
+    case CK_PER_CHAIN: {
+      // Launches whose working set (state + packed factor) cannot stay in the Infinity Cache read the factor
+      // non-temporally (CK_PER_CHAIN_NT): streamed with the default policy it evicts the chain state, which then goes to
+      // HBM as well (16 real parameters, 2^20 chains: 146 -> 114 us).  Smaller working sets keep the default policy --
+      // there the factor IS resident from launch to launch and nt would send it to HBM (config 3: 33 -> 38 us).
+      constexpr long long per_chain_bytes = (long long)sizeof(R) * (D + 2 + NR * (NR + 1) / 2 + NC * NC);
+      if constexpr (!INJECT) {
+        if (per_chain_bytes * l.n > kInfinityCacheBudget) {
+          hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_PER_CHAIN_NT, INJECT, GROUP>), grid, block, 0, stream, a, en);
+          break;
+        }
+      }
+      hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_PER_CHAIN, INJECT, GROUP>), grid, block, 0, stream, a, en);
+      break;
+    }
 #endif
     default: return hipErrorInvalidValue;
   }
@@ -352,12 +366,20 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
   constexpr int P = NR * (NR + 1) / 2 + NC * NC;
   constexpr bool kFused = ME_PER_CHAIN != 0 && P <= ME_MEASURE_FUSED_MAX_P;
   const dim3 grid(grid_for(l.n, l.grid_blocks)), block(kStepThreads);
-  if (l.cov) hipLaunchKernelGGL((k_measure<R, NR, NC, (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0), kFused>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((k_measure<R, NR, NC, false, false>), grid, block, 0, stream, a);
+  // working set of a measure: x, mean, observables, covariance (+ factor); beyond the Infinity Cache the packed fields
+  // are streamed non-temporally (me_device.h: Field::load_nt)
+  constexpr long long per_chain_bytes = (long long)sizeof(R) * (2 * D + (2 * NR + NC) + 2 * P);
+  const bool nt = per_chain_bytes * l.n > kInfinityCacheBudget;
+  constexpr bool kCov = (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0);
+  if (l.cov && nt) hipLaunchKernelGGL((k_measure<R, NR, NC, kCov, kFused, true>), grid, block, 0, stream, a);
+  else if (l.cov) hipLaunchKernelGGL((k_measure<R, NR, NC, kCov, kFused, false>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((k_measure<R, NR, NC, false, false, false>), grid, block, 0, stream, a);
 #if ME_PER_CHAIN
   if constexpr (!kFused) {
-    if (l.update_cov && l.write_factor)
-      hipLaunchKernelGGL((k_factor<R, NR, NC>), grid, block, 0, stream, (const R *)l.cov, (R *)l.factor, l.status, l.n);
+    if (l.update_cov && l.write_factor) {
+      if (nt) hipLaunchKernelGGL((k_factor<R, NR, NC, true>), grid, block, 0, stream, (const R *)l.cov, (R *)l.factor, l.status, l.n);
+      else hipLaunchKernelGGL((k_factor<R, NR, NC, false>), grid, block, 0, stream, (const R *)l.cov, (R *)l.factor, l.status, l.n);
+    }
   }
 #endif
   return hipGetLastError();
