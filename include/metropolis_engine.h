@@ -179,6 +179,9 @@ int me_constants(me_engine *engine, double *alpha, int32_t *m, double *ratio);
 int me_counters(me_engine *engine, uint64_t *step_index, uint64_t *measure_step_counter);
 int me_set_counters(me_engine *engine, uint64_t step_index, uint64_t measure_step_counter);
 int me_accept_stats(me_engine *engine, uint64_t *accepted, uint64_t *proposed);
+/* Restore the acceptance counters of a checkpoint (the reference has no counterpart: its only resume is the constructor
+ * warm start, metropolis_engine.py:17). */
+int me_set_accept_stats(me_engine *engine, uint64_t accepted, uint64_t proposed);
 
 /* Ensemble sums over the local chains, fp64:
  *   [ n, sum x (D), sum x x^T (D(D+1)/2, row-major lower triangle), sum obs (2nr+nc), accepted, proposed ]
@@ -196,6 +199,9 @@ int me_pooled_moments_begin(me_engine *engine);
 int me_pooled_moments_end(me_engine *engine, double *host_out, int64_t n_doubles);
 /* Install the shared proposal factor of ME_COV_POOLED: packed like ME_FIELD_FACTOR, [P] doubles. */
 int me_set_shared_factor(me_engine *engine, const double *packed_factor, int64_t n_doubles);
+/* The factor last installed with me_set_shared_factor ([P] doubles, exactly as given); *is_set = 0 and the buffer is left
+ * alone when none has been installed.  Part of a checkpoint of a ME_COV_POOLED engine. */
+int me_get_shared_factor(me_engine *engine, double *packed_factor, int64_t n_doubles, int32_t *is_set);
 
 /* Time series (metropolis_engine.py:350-356, :466-479): every me_measure appends one row per traced chain
  * (chains t*stride, t < n_traced) to a device-side series; me_trace_get returns it as doubles

@@ -123,6 +123,7 @@ struct me_engine {
   unsigned long long chain_offset = 0, seed = 0;
   double temp = 0, target_acceptance = 0.3, alpha = 0, ratio = 0, reject_bound = 0;
   int m = 0, energy_kind = 0, reject_kind = 0, cov_mode = 0;
+  std::vector<double> shared_host;   // the packed factor last given to me_set_shared_factor (empty: none); checkpoints
   int cov_kind = CK_IDENTITY;
   int grid_blocks = 0;
   int n_terms = 1;   // rows of the energy ledger (KernelSet::energy_terms)
@@ -339,6 +340,11 @@ int me_create(const me_config *c, me_engine **out) {
     return fail(nullptr, ME_ERR_UNSUPPORTED, "energy kind " + std::to_string(c->energy_kind) +
                                                   " is not compiled for these dimensions");
   }
+  // the reference evaluates reject_condition BEFORE the energy (metropolis_engine.py:247-249); a plugin without
+  // me_user_reject would silently never reject and let chains walk into the forbidden region
+  if (c->reject_kind == ME_REJECT_USER && !ks->has_user_reject)
+    return fail(nullptr, ME_ERR_UNSUPPORTED,
+                "ME_REJECT_USER: this user-energy plugin defines no me_user_reject (#define ME_USER_HAS_REJECT in its source)");
   if (c->cov_mode == ME_COV_REFERENCE && !ks->per_chain_cov)
     return fail(nullptr, ME_ERR_UNSUPPORTED,
                 "per-chain adaptive covariance is not compiled for these dimensions; use ME_COV_FIXED or ME_COV_POOLED");
@@ -520,6 +526,9 @@ int me_set_reject_condition(me_engine *e, int32_t reject_kind, double reject_bou
   if (reject_kind < ME_REJECT_NONE || reject_kind > ME_REJECT_USER) return fail(e, ME_ERR_INVALID, "unknown reject_kind");
   if (reject_kind == ME_REJECT_USER && e->energy_kind != ME_ENERGY_USER && e->energy_kind != ME_ENERGY_USER_INDIRECT)
     return fail(e, ME_ERR_INVALID, "ME_REJECT_USER needs a user-energy plugin (it supplies me_user_reject)");
+  if (reject_kind == ME_REJECT_USER && !e->ks->has_user_reject)
+    return fail(e, ME_ERR_UNSUPPORTED,
+                "ME_REJECT_USER: this user-energy plugin defines no me_user_reject (#define ME_USER_HAS_REJECT in its source)");
   if (reject_kind == ME_REJECT_ABS_REAL0_GE && e->nr == 0)
     return fail(e, ME_ERR_INVALID, "ME_REJECT_ABS_REAL0_GE needs a real parameter");
   e->reject_kind = reject_kind;     // a launch parameter: takes effect from the next step
@@ -666,7 +675,7 @@ int me_step_injected(me_engine *e, int32_t kind, int32_t n_sweeps, const double 
 int me_measure(me_engine *e) {
   if (!e) return ME_ERR_INVALID;
   ME_HIP(e, hipSetDevice(e->device));
-  e->measure_count += 1;   // metropolis_engine.py:343
+  const unsigned long long count = e->measure_count + 1;   // metropolis_engine.py:343; committed once the launch succeeded
   MeasureLaunch l;
   l.x = e->x;
   l.width = e->width;
@@ -676,12 +685,13 @@ int me_measure(me_engine *e) {
   l.factor = e->factor;
   l.status = e->status;
   l.n = e->n;
-  l.measure_count = e->measure_count;
-  l.update_cov = (e->measure_count > 50 && e->cov) ? 1 : 0;   // :389, :396
+  l.measure_count = count;
+  l.update_cov = (count > 50 && e->cov) ? 1 : 0;   // :389, :396
   l.split_widths = (e->width_rows == 3 && !e->widths_synced) ? 1 : 0;
   l.write_factor = (l.update_cov && e->cov_mode == ME_COV_REFERENCE) ? 1 : 0;
   l.grid_blocks = e->grid_blocks;
   ME_HIP(e, e->ks->measure(l, e->stream));
+  e->measure_count = count;
   if (l.write_factor) e->cov_kind = CK_PER_CHAIN;
   if (e->trace_chains > 0) {
     const long long cols = e->d + e->n_terms + e->width_rows;
@@ -798,6 +808,9 @@ int me_set(me_engine *e, int32_t field, int64_t chain_begin, int64_t n_chains, c
   int comps;
   int rc = field_info(e, field, &ptr, &comps);
   if (rc != ME_OK) return rc;
+  // every argument check comes before the first device write
+  if (field == ME_FIELD_WIDTH && e->width_rows == 3 && (chain_begin != 0 || n_chains != e->n))
+    return fail(e, ME_ERR_INVALID, "widths of a mixed engine must be set for all chains at once");
   if (n_chains == 0) return ME_OK;
   std::vector<unsigned char> tmp((size_t)comps * n_chains * e->esize);
   if (e->dtype == ME_F32) {
@@ -815,10 +828,7 @@ int me_set(me_engine *e, int32_t field, int64_t chain_begin, int64_t n_chains, c
                              hipMemcpyHostToDevice, e->stream));
   ME_HIP(e, hipStreamSynchronize(e->stream));
   if (field == ME_FIELD_FACTOR) e->cov_kind = CK_PER_CHAIN;
-  if (field == ME_FIELD_WIDTH && e->width_rows == 3) {
-    if (chain_begin != 0 || n_chains != e->n) return fail(e, ME_ERR_INVALID, "widths of a mixed engine must be set for all chains at once");
-    e->widths_synced = false;
-  }
+  if (field == ME_FIELD_WIDTH && e->width_rows == 3) e->widths_synced = false;
   return ME_OK;
 }
 
@@ -855,6 +865,19 @@ int me_accept_stats(me_engine *e, uint64_t *accepted, uint64_t *proposed) {
   if (accepted) *accepted = e->host_scratch[1];
   if (proposed) *proposed = e->proposed;
   return report_status(e, (unsigned int)e->host_scratch[0]);
+}
+
+int me_set_accept_stats(me_engine *e, uint64_t accepted, uint64_t proposed) {
+  if (!e) return ME_ERR_INVALID;
+  if (accepted > proposed) return fail(e, ME_ERR_INVALID, "accepted exceeds proposed");
+  ME_HIP(e, hipSetDevice(e->device));
+  // the device keeps one counter per wavefront, summed on demand: all of them to zero, the total into the first
+  const unsigned long long total = accepted;
+  ME_HIP(e, hipMemsetAsync(e->accept_slots, 0, (size_t)e->n_slots * sizeof(unsigned long long), e->stream));
+  ME_HIP(e, hipMemcpyAsync(e->accept_slots, &total, sizeof(total), hipMemcpyHostToDevice, e->stream));
+  ME_HIP(e, hipStreamSynchronize(e->stream));
+  e->proposed = proposed;
+  return ME_OK;
 }
 
 int me_pooled_moments_size(me_engine *e, int64_t *n_doubles) {
@@ -937,6 +960,16 @@ int me_set_shared_factor(me_engine *e, const double *packed_factor, int64_t n_do
   int rc = upload_shared_factor(e, packed_factor);
   if (rc != ME_OK) return rc;
   e->cov_kind = CK_SHARED;
+  e->shared_host.assign(packed_factor, packed_factor + n_doubles);
+  return ME_OK;
+}
+
+int me_get_shared_factor(me_engine *e, double *packed_factor, int64_t n_doubles, int32_t *is_set) {
+  if (!e || !is_set) return ME_ERR_INVALID;
+  *is_set = e->shared_host.empty() ? 0 : 1;
+  if (!*is_set) return ME_OK;
+  if (!packed_factor || n_doubles != e->p) return fail(e, ME_ERR_INVALID, "wrong packed factor length");
+  std::copy(e->shared_host.begin(), e->shared_host.end(), packed_factor);
   return ME_OK;
 }
 

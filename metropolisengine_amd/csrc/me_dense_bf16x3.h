@@ -305,21 +305,26 @@ inline bool dense64_exact_fp32_mfma() {
 template <int CK, int THREADS>
 inline hipError_t launch_step_dense64_bf16x3_threads(const StepArgs<float> &a, const unsigned int *afrag,
                                                      const unsigned int *lfrag, int grid_blocks, hipStream_t stream) {
-  static const hipError_t attr = hipFuncSetAttribute((const void *)k_step_dense64_bf16x3<CK, THREADS>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)dense64_bf16_lds_bytes<CK, THREADS>());
-  if (attr != hipSuccess) return attr;
+  // per DEVICE of the process, not per process (me_per_device.h): the raised dynamic-LDS limit and the CU count
+  static PerDevice<hipError_t> attr_cache;
+  static PerDevice<int> cu_cache;
+  int device = 0;
+  hipError_t rc = hipGetDevice(&device);
+  if (rc != hipSuccess) return rc;
+  rc = attr_cache.get(device, [] {
+    return hipFuncSetAttribute((const void *)k_step_dense64_bf16x3<CK, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)dense64_bf16_lds_bytes<CK, THREADS>());
+  });
+  if (rc != hipSuccess) return rc;
   // Persistent workgroups, four wavefront-slots' worth per SIMD pair (two 512-thread or four 256-thread groups per CU),
   // each striding over its tiles with the next tile's loads issued before the current one retires: beats one group per
   // tile by 12 % at one sweep per launch (start-up: image copy + barrier with nothing else resident) and ties when
   // sweeps are fused.  tools/dev/time_dense64_grid.py
-  static const int cus = [] {
-    int device = 0, count = 0;
-    if (hipGetDevice(&device) != hipSuccess ||
-        hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || count <= 0)
-      return 256;
+  const int cus = cu_cache.get(device, [device] {
+    int count = 0;
+    if (hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || count <= 0) return 256;
     return count;
-  }();
+  });
   long long blocks = (a.n + THREADS - 1) / THREADS;
   const long long cap = grid_blocks > 0 ? grid_blocks : (long long)cus * (1024 / THREADS);
   if (blocks > cap) blocks = cap;

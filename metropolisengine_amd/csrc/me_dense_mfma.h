@@ -21,6 +21,7 @@
 #pragma once
 
 #include "me_device.h"
+#include "me_per_device.h"
 
 namespace me {
 
@@ -252,10 +253,15 @@ __global__ void __launch_bounds__(kDenseBlockThreads, 2) k_step_dense64_mfma(Ste
 template <int CK>
 inline hipError_t launch_step_dense64_mfma(const StepArgs<float> &a, const float *amat, const float *lfull, int grid_blocks,
                                            hipStream_t stream) {
-  static const hipError_t attr = hipFuncSetAttribute((const void *)k_step_dense64_mfma<CK>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)dense64_lds_bytes<CK>());
-  if (attr != hipSuccess) return attr;
+  static PerDevice<hipError_t> attr_cache;      // per device of the process (me_per_device.h)
+  int device = 0;
+  hipError_t rc = hipGetDevice(&device);
+  if (rc != hipSuccess) return rc;
+  rc = attr_cache.get(device, [] {
+    return hipFuncSetAttribute((const void *)k_step_dense64_mfma<CK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)dense64_lds_bytes<CK>());
+  });
+  if (rc != hipSuccess) return rc;
   long long blocks = (a.n + kDenseBlockThreads - 1) / kDenseBlockThreads;
   if (grid_blocks > 0 && blocks > grid_blocks) blocks = grid_blocks;
   hipLaunchKernelGGL(k_step_dense64_mfma<CK>, dim3((unsigned)blocks), dim3(kDenseBlockThreads), dense64_lds_bytes<CK>(),

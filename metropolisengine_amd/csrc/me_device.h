@@ -698,7 +698,12 @@ __device__ __forceinline__ void cholesky_packed(R (&m)[NR * (NR + 1) / 2 + NC * 
 #ifndef ME_MEASURE_WAVES
 #define ME_MEASURE_WAVES 1
 #endif
-template <typename R, int NR, int NC, bool PER_CHAIN_COV, bool FUSED, bool NT>
+// NT: the packed covariance / factor fields are accessed non-temporally; NTM: the running means and observables too.
+// Both are decided per launch from the sizes (me_kernels.hip: measure): a field goes nt when the fields that COULD stay
+// resident in the Infinity Cache between launches no longer fit together with it.  Measured at 2^20 x (16,0): packed
+// fields nt 468 -> 375 us, means nt on top of that 375 -> 410 us (x + means + observables = 256 MB still profit from the
+// cache); at 2^19 x (64,0), means only: 225 -> 190 us with nt (537 MB: keeping x resident for the next k_step wins).
+template <typename R, int NR, int NC, bool PER_CHAIN_COV, bool FUSED, bool NT, bool NTM>
 __global__ void __launch_bounds__(kStepThreads, ME_MEASURE_WAVES) k_measure(MeasureArgs<R> a) {
   constexpr int D = NR + 2 * NC;
   constexpr int PR = NR * (NR + 1) / 2;
@@ -725,12 +730,12 @@ __global__ void __launch_bounds__(kStepThreads, ME_MEASURE_WAVES) k_measure(Meas
 #pragma unroll
       for (int d = 0; d < D; ++d) x[d] = fx.load(d, coff);
 #pragma unroll
-      for (int d = 0; d < D; ++d) mu[d] = fmean.load(d, coff);
+      for (int d = 0; d < D; ++d) mu[d] = packed_load<NTM>(fmean, d, coff);
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         if constexpr (STREAM) s_delta[d][threadIdx.x] = x[d] - mu[d];   // parked in LDS, see the streaming path below
         else delta[d] = x[d] - mu[d];
-        fmean.store(d, coff, mu[d] * a.keep + x[d] * a.inv_i);   // :404-410
+        packed_store<NTM>(fmean, d, coff, mu[d] * a.keep + x[d] * a.inv_i);   // :404-410
       }
     }
     // observables [|x_r|, |z_c|, x_r^2] and their running mean (:458-463, :412-414), in batches of kBatch
@@ -740,7 +745,7 @@ __global__ void __launch_bounds__(kStepThreads, ME_MEASURE_WAVES) k_measure(Meas
       R m[kBatch];
 #pragma unroll
       for (int u = 0; u < kBatch; ++u)
-        if (k0 + u < NOBS) m[u] = fobs.load(k0 + u, coff);
+        if (k0 + u < NOBS) m[u] = packed_load<NTM>(fobs, k0 + u, coff);
 #pragma unroll
       for (int u = 0; u < kBatch; ++u) {
         const int k = k0 + u;
@@ -749,7 +754,7 @@ __global__ void __launch_bounds__(kStepThreads, ME_MEASURE_WAVES) k_measure(Meas
           if (k < NR) o = N_::abs_(x[k]);
           else if (k < NR + NC) o = N_::sqrt_(x[k] * x[k] + x[k + NC] * x[k + NC]);
           else o = x[k - NR - NC] * x[k - NR - NC];
-          fobs.store(k, coff, m[u] * a.keep + o * a.inv_i);
+          packed_store<NTM>(fobs, k, coff, m[u] * a.keep + o * a.inv_i);
         }
       }
     }

@@ -104,6 +104,8 @@ struct KernelSet {
   // optional: a dimension-specific first stage of the pooled-moment reduction writing partials[row][entry] for
   // n_rows rows in k_pool_finish's entry order (nullptr: the generic k_pool_reduce)
   hipError_t (*pool_stage1)(const void *x, long long n, double *partials, int n_rows, hipStream_t);
+  // user-energy sets only: the plugin source defines me_user_reject (ME_USER_HAS_REJECT), so ME_REJECT_USER means something
+  bool has_user_reject;
 };
 
 void register_kernel_set(const KernelSet *set);

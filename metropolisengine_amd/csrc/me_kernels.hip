@@ -266,7 +266,11 @@ hipError_t with_energy(int kind, const double *coef, int n_coef, const void *coe
     return f(en);
   }
   if (kind == ME_ENERGY_USER_INDIRECT) {
-    static const user_fn_t<R> fn = load_user_fn<R>();
+    // the pointer is an address inside THIS device's copy of the plugin's code object: resolve it per device
+    static PerDevice<user_fn_t<R>> fn_cache;
+    int device = 0;
+    if (hipError_t rc = hipGetDevice(&device); rc != hipSuccess) return rc;
+    const user_fn_t<R> fn = fn_cache.get(device, [] { return load_user_fn<R>(); });
     if (!fn) return hipErrorInvalidDeviceFunction;
     EnergyUserIndirect<R, NR, NC> en{fn, (const R *)coef_device};
     return f(en);
@@ -366,14 +370,21 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
   constexpr int P = NR * (NR + 1) / 2 + NC * NC;
   constexpr bool kFused = ME_PER_CHAIN != 0 && P <= ME_MEASURE_FUSED_MAX_P;
   const dim3 grid(grid_for(l.n, l.grid_blocks)), block(kStepThreads);
-  // working set of a measure: x, mean, observables, covariance (+ factor); beyond the Infinity Cache the packed fields
-  // are streamed non-temporally (me_device.h: Field::load_nt)
-  constexpr long long per_chain_bytes = (long long)sizeof(R) * (2 * D + (2 * NR + NC) + 2 * P);
-  const bool nt = per_chain_bytes * l.n > kInfinityCacheBudget;
+  // Cache policy by size (k_measure's comment in me_device.h): the packed fields go non-temporal when the whole working
+  // set (x, means, observables, covariance, factor) exceeds the Infinity Cache; the means and observables too when even
+  // x + means + observables do.
+  constexpr long long mean_bytes = (long long)sizeof(R) * (2 * D + (2 * NR + NC));
+  constexpr long long all_bytes = mean_bytes + (long long)sizeof(R) * 2 * P;
+  const bool nt = all_bytes * l.n > kInfinityCacheBudget, ntm = mean_bytes * l.n > kInfinityCacheBudget;
   constexpr bool kCov = (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0);
-  if (l.cov && nt) hipLaunchKernelGGL((k_measure<R, NR, NC, kCov, kFused, true>), grid, block, 0, stream, a);
-  else if (l.cov) hipLaunchKernelGGL((k_measure<R, NR, NC, kCov, kFused, false>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((k_measure<R, NR, NC, false, false, false>), grid, block, 0, stream, a);
+  if (l.cov) {
+    if (ntm) hipLaunchKernelGGL((k_measure<R, NR, NC, kCov, kFused, true, true>), grid, block, 0, stream, a);
+    else if (nt) hipLaunchKernelGGL((k_measure<R, NR, NC, kCov, kFused, true, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_measure<R, NR, NC, kCov, kFused, false, false>), grid, block, 0, stream, a);
+  } else {
+    if (ntm) hipLaunchKernelGGL((k_measure<R, NR, NC, false, false, false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_measure<R, NR, NC, false, false, false, false>), grid, block, 0, stream, a);
+  }
 #if ME_PER_CHAIN
   if constexpr (!kFused) {
     if (l.update_cov && l.write_factor) {
@@ -420,12 +431,17 @@ constexpr size_t kMatrixImageBytesF64 = (NR == 64 && NC == 0) ? sizeof(double) *
 #define ME_PREPARE_MATRIX_F32 0, nullptr, pool_stage1_f32()
 #define ME_PREPARE_MATRIX_F64 0, nullptr, nullptr
 #endif
+#ifdef ME_USER_HAS_REJECT
+constexpr bool kHasUserReject = true;
+#else
+constexpr bool kHasUserReject = false;
+#endif
 const KernelSet kSetF32 = {ME_SET_NAME, ME_F32, NR, NC, ME_PER_CHAIN != 0, (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0), has_energy, energy_terms, step<float>,
                            (NC > 0 && ME_PER_CHAIN) ? magphase<float> : nullptr, measure<float>, init_energy<float>,
-                           ME_PREPARE_MATRIX_F32};
+                           ME_PREPARE_MATRIX_F32, kHasUserReject};
 const KernelSet kSetF64 = {ME_SET_NAME, ME_F64, NR, NC, ME_PER_CHAIN != 0, (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0), has_energy, energy_terms, step<double>,
                            (NC > 0 && ME_PER_CHAIN) ? magphase<double> : nullptr, measure<double>, init_energy<double>,
-                           ME_PREPARE_MATRIX_F64};
+                           ME_PREPARE_MATRIX_F64, kHasUserReject};
 
 struct Registrar {
   Registrar() {

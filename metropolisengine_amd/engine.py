@@ -427,6 +427,14 @@ class MetropolisEngine:
         """Write the local ensemble sums into caller-owned device memory (e.g. a torch CUDA tensor's data_ptr)."""
         self._check(self._lib.me_pooled_moments_device(self._handle, ctypes.c_void_p(device_ptr), int(n_doubles)))
 
+    def shared_factor(self):
+        """The packed factor last installed with :meth:`set_shared_factor`, or ``None``."""
+        nr, nc = self.num_real_params, self.num_complex_params
+        out = np.empty(nr * (nr + 1) // 2 + nc * nc, dtype=np.float64)
+        is_set = ctypes.c_int32()
+        self._check(self._lib.me_get_shared_factor(self._handle, _as_double_ptr(out), out.size, ctypes.byref(is_set)))
+        return out if is_set.value else None
+
     def set_shared_factor(self, packed_factor):
         f = np.ascontiguousarray(packed_factor, dtype=np.float64)
         self._check(self._lib.me_set_shared_factor(self._handle, _as_double_ptr(f), f.size))
@@ -459,6 +467,10 @@ class MetropolisEngine:
         step, meas = self._counters()
         state["step_index"], state["measure_step_counter"] = step, meas
         state["uses_per_chain_factors"] = bool(meas > 50 and self.cov_mode == "reference")
+        state["accepted"], state["proposed"] = self.accept_stats()
+        shared = self.shared_factor()
+        if shared is not None:                       # cov_mode="pooled": the proposal shape every chain shares
+            state["shared_factor"] = shared
         return state
 
     def load_state_dict(self, state):
@@ -467,8 +479,11 @@ class MetropolisEngine:
                 self._set(field, state[name])
         self._check(self._lib.me_set_counters(self._handle, int(state["step_index"]),
                                               int(state["measure_step_counter"])))
+        if "shared_factor" in state:
+            self.set_shared_factor(state["shared_factor"])
+        if "accepted" in state and "proposed" in state:
+            self._check(self._lib.me_set_accept_stats(self._handle, int(state["accepted"]), int(state["proposed"])))
 
-    # ------------------------------------------------------------------ out of scope this round
     # ------------------------------------------------------------------ time series (:31-35, :350-356, :466-479)
     def trace(self):
         """Recorded series as ``[n_measures, n_traced, D + n_terms + n_widths]``: params, energy terms, widths per

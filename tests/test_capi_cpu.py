@@ -118,3 +118,41 @@ def test_user_energy_plugin_loads_and_registers():
     assert "no_such_plugin" in _capi.last_error()
     cfg.user_energy_name = b"cylinder"
     assert lib.me_create(ctypes.byref(cfg), ctypes.byref(handle)) == _capi.ME_ERR_HIP   # found; no GPU here
+
+
+def test_reject_user_needs_a_plugin_with_a_reject_function():
+    """ME_REJECT_USER on a plugin that defines no me_user_reject is refused (the wall would otherwise be dropped silently
+    and chains could walk into the forbidden region; the reference evaluates reject_condition before the energy,
+    metropolis_engine.py:247-249).  examples/user_energy_landau_terms.h has none; examples/user_energy_cylinder.h does."""
+    from metropolisengine_amd import build
+    lib = _capi.load()
+    for name, nr, nc in (("landau_terms", 2, 1), ("cylinder", 2, 7)):
+        assert lib.me_load_plugin(build.user_plugin_path(name, nr, nc).encode()) == _capi.ME_OK
+    handle = ctypes.c_void_p()
+    coef = np.ones(3)
+
+    def create(name, nr, nc):
+        cfg = _capi.MeConfig()
+        init = np.zeros(nr + 2 * nc)
+        cfg.abi_version, cfg.n_chains, cfg.n_real, cfg.n_complex = _capi.ABI_VERSION, 8, nr, nc
+        cfg.target_acceptance, cfg.sampling_width, cfg.temp = 0.3, 0.05, 0.1
+        cfg.energy_kind, cfg.n_energy_coeffs = _capi.ENERGY_USER, 3
+        cfg.energy_coeffs = coef.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        cfg.initial_params = init.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        cfg.user_energy_name = name
+        cfg.reject_kind = _capi.REJECT_USER
+        return lib.me_create(ctypes.byref(cfg), ctypes.byref(handle))
+
+    assert create(b"landau_terms", 2, 1) == _capi.ME_ERR_UNSUPPORTED
+    assert "me_user_reject" in _capi.last_error()
+    assert create(b"cylinder", 2, 7) == _capi.ME_ERR_HIP          # accepted; no GPU here
+
+
+def test_per_device_cache_is_keyed_by_device(tmp_path):
+    """Launch properties resolved lazily (a __device__ function pointer, the raised dynamic-LDS limit, the CU count) are
+    cached per DEVICE of the process, not per process (csrc/me_per_device.h)."""
+    import subprocess
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "per_device_host.cpp")
+    out = str(tmp_path / "libper_device.so")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", src, "-o", out, "-pthread"], check=True)
+    assert ctypes.CDLL(out).me_test_per_device() == 0

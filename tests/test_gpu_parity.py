@@ -245,6 +245,42 @@ def test_checkpoint_round_trip():
         assert np.array_equal(a._get(field), b._get(field)), field
 
 
+def test_checkpoint_round_trip_pooled_shape_and_counters():
+    """cov_mode="pooled": the shared proposal factor and the acceptance counters are part of the checkpoint; a resumed run
+    continues the uninterrupted trajectory bit for bit."""
+    from metropolisengine_amd.distributed import adapt_pooled_shape
+    args = (me.DiagQuadratic((1, 2, 4, 8), (1, 2, 4, 8)), None, [0.0] * 4, [0j] * 4)
+    kw = dict(temp=1.0, n_chains=700, seed=10, cov_mode="pooled")
+    a = me.MetropolisEngine(*args, **kw)
+    a.step_all(300)
+    assert a.shared_factor() is None and "shared_factor" not in a.state_dict()
+    adapt_pooled_shape(a)
+    a.step_all(40)
+    a.measure()
+    state = a.state_dict()
+    assert state["shared_factor"].shape == (4 * 5 // 2 + 16,) and state["proposed"] == 700 * 340
+    b = me.MetropolisEngine(*args, **kw)
+    b.load_state_dict(state)
+    assert b.accept_stats() == a.accept_stats()
+    for e in (a, b):
+        e.step_all(25)
+        e.measure()
+    for field in range(5):
+        assert np.array_equal(a._get(field), b._get(field)), field
+    assert a.accept_stats() == b.accept_stats()
+    assert np.array_equal(a.shared_factor(), b.shared_factor())
+
+
+def test_set_rejects_partial_mixed_widths_before_writing():
+    """me_set validates before any device write: a partial width update of a mixed engine leaves the widths untouched."""
+    eng = me.MetropolisEngine(me.DiagQuadratic((1, 2), (1, 2)), None, [0.0] * 2, [0j] * 2, temp=1.0, n_chains=64, seed=3)
+    eng.step_all(20)
+    before = eng._get(2)
+    with pytest.raises(ValueError):
+        eng._set(2, np.full((10, 3), 7.0), chain_begin=5)
+    assert np.array_equal(eng._get(2), before)
+
+
 def test_reference_api_surface_single_chain():
     """README.md:26-51 transcribed: one real parameter, E = x^2, T = 0.01, 1000 x (step_all, measure)."""
     eng = me.MetropolisEngine(me.IsoQuadratic(1.0), initial_real_params=[0.0], temp=.01, seed=12345, dtype="f64")
