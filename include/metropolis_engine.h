@@ -199,6 +199,10 @@ int me_pooled_moments_begin(me_engine *engine);
 int me_pooled_moments_end(me_engine *engine, double *host_out, int64_t n_doubles);
 /* Install the shared proposal factor of ME_COV_POOLED: packed like ME_FIELD_FACTOR, [P] doubles. */
 int me_set_shared_factor(me_engine *engine, const double *packed_factor, int64_t n_doubles);
+/* Tuning knob (process-wide, default 224 MiB): launches whose working set exceeds this many bytes access their read-once
+ * / write-once fields (packed covariance and factors, large running-mean fields) with the non-temporal cache policy, so
+ * that the chain state stays resident in the 256 MiB Infinity Cache; 0 = always, a huge value = never. */
+int me_set_cache_budget(int64_t bytes);
 /* The factor last installed with me_set_shared_factor ([P] doubles, exactly as given); *is_set = 0 and the buffer is left
  * alone when none has been installed.  Part of a checkpoint of a ME_COV_POOLED engine. */
 int me_get_shared_factor(me_engine *engine, double *packed_factor, int64_t n_doubles, int32_t *is_set);

@@ -6,8 +6,8 @@ The HIP library is loaded on first use of an engine; there is no CPU fallback.
 """
 from .energy import (AbsReal0AtLeast, CylinderSurrogate, DenseQuadratic, DiagQuadratic, EnergySpec, IsoQuadratic,
                      LandauToy, RejectSpec, UserEnergy, UserReject)
-from .engine import MetropolisEngine
+from .engine import MetropolisEngine, set_cache_budget
 
-__all__ = ["MetropolisEngine", "EnergySpec", "IsoQuadratic", "DiagQuadratic", "DenseQuadratic", "LandauToy",
+__all__ = ["MetropolisEngine", "set_cache_budget", "EnergySpec", "IsoQuadratic", "DiagQuadratic", "DenseQuadratic", "LandauToy",
            "CylinderSurrogate", "UserEnergy", "RejectSpec", "AbsReal0AtLeast", "UserReject"]
 __version__ = "0.1.0"

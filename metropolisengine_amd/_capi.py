@@ -70,6 +70,7 @@ SYMBOLS = {
     "me_set_shared_factor": (ctypes.c_int, [_H, _dp, ctypes.c_int64]),
     "me_get_shared_factor": (ctypes.c_int, [_H, _dp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32)]),
     "me_set_accept_stats": (ctypes.c_int, [_H, ctypes.c_uint64, ctypes.c_uint64]),
+    "me_set_cache_budget": (ctypes.c_int, [ctypes.c_int64]),
     "me_trace_enable": (ctypes.c_int, [_H, ctypes.c_int64, ctypes.c_int64]),
     "me_trace_shape": (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                       ctypes.POINTER(ctypes.c_int64)]),

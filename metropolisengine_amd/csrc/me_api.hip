@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 #include <mutex>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "me_internal.h"
@@ -294,7 +295,21 @@ void release(me_engine *e) {
 
 }  // namespace
 
+namespace me {
+namespace {
+std::atomic<long long> g_cache_budget{224ll << 20};
+}
+long long cache_budget_bytes() { return g_cache_budget.load(std::memory_order_relaxed); }
+void set_cache_budget_bytes(long long bytes) { g_cache_budget.store(bytes, std::memory_order_relaxed); }
+}  // namespace me
+
 extern "C" {
+
+int me_set_cache_budget(int64_t bytes) {
+  if (bytes < 0) return fail(nullptr, ME_ERR_INVALID, "cache budget must be >= 0");
+  me::set_cache_budget_bytes(bytes);
+  return ME_OK;
+}
 
 int me_abi_version(void) { return ME_ABI_VERSION; }
 

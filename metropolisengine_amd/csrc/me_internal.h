@@ -25,8 +25,10 @@ enum StatusBits : uint32_t {
 };
 
 // A kernel whose per-launch working set stays below this is served from the 256 MiB Infinity Cache from launch to
-// launch (measured: 151 MB and 226 MB sets stay resident, MI355X_MICROARCH.md); larger ones stream from HBM.
-constexpr long long kInfinityCacheBudget = 224ll << 20;
+// launch (measured: 151 MB and 226 MB sets stay resident, MI355X_MICROARCH.md); larger ones stream from HBM and their
+// read-once / write-once fields are accessed non-temporally.  A process-wide tuning knob (me_set_cache_budget).
+long long cache_budget_bytes();
+void set_cache_budget_bytes(long long bytes);
 
 constexpr int kBlockThreads = 256;  // block size of the dimension-independent kernels (me_generic.hip)
 // Block size of the per-chain kernels (k_step, k_measure, ...): one lane owns one chain.  Measured on MI355X at

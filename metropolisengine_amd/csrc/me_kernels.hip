@@ -166,7 +166,7 @@ hipError_t launch_step_cov(const StepLaunch &l, const StepArgs<R> &a, const Ener
       // there the factor IS resident from launch to launch and nt would send it to HBM (config 3: 33 -> 38 us).
       constexpr long long per_chain_bytes = (long long)sizeof(R) * (D + 2 + NR * (NR + 1) / 2 + NC * NC);
       if constexpr (!INJECT) {
-        if (per_chain_bytes * l.n > kInfinityCacheBudget) {
+        if (per_chain_bytes * l.n > cache_budget_bytes()) {
           hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_PER_CHAIN_NT, INJECT, GROUP>), grid, block, 0, stream, a, en);
           break;
         }
@@ -375,7 +375,7 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
   // x + means + observables do.
   constexpr long long mean_bytes = (long long)sizeof(R) * (2 * D + (2 * NR + NC));
   constexpr long long all_bytes = mean_bytes + (long long)sizeof(R) * 2 * P;
-  const bool nt = all_bytes * l.n > kInfinityCacheBudget, ntm = mean_bytes * l.n > kInfinityCacheBudget;
+  const bool nt = all_bytes * l.n > cache_budget_bytes(), ntm = mean_bytes * l.n > cache_budget_bytes();
   constexpr bool kCov = (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0);
   if (l.cov) {
     if (ntm) hipLaunchKernelGGL((k_measure<R, NR, NC, kCov, kFused, true, true>), grid, block, 0, stream, a);

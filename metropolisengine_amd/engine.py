@@ -62,6 +62,12 @@ def unpack_real_factor(packed, nr):
     return out
 
 
+def set_cache_budget(n_bytes):
+    """Process-wide tuning knob (``me_set_cache_budget``): launches whose working set exceeds ``n_bytes`` stream their
+    read-once / write-once fields with the non-temporal cache policy.  Default 224 MiB."""
+    _capi.check(_capi.load().me_set_cache_budget(int(n_bytes)))
+
+
 class MetropolisEngine:
     def __init__(self, energy_functions, reject_condition=None, initial_real_params=None,
                  initial_complex_params=None, sampling_width=0.05, covariance_matrix_real=None,
