@@ -18,7 +18,13 @@ Everything else -- the proposal covariances it builds, the accept rule, width
 adaptation, running mean / covariance / observables -- is the reference's own
 code.  A second set of anchors uses the reference's legacy seeded RNG unpatched.
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+Usage:  PYTHONHASHSEED=0 PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py            # rewrite tests/golden/
+        PYTHONHASHSEED=0 PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py --check    # regenerate into a temporary
+                                                   directory and compare every array with the committed fixtures
+
+PYTHONHASHSEED=0 is required: the reference iterates a ``set`` of energy-term names when it records the per-term energy
+series (metropolis_engine.py:112-114), so the ORDER of its ``<term>_energy`` DataFrame columns follows the hash seed; with
+the seed pinned the fixtures are reproducible bit for bit.
 """
 import math
 import os
@@ -159,7 +165,7 @@ def run_scenario(me, name, spec, stream_seed):
     path = os.path.join(GOLDEN_DIR, "traj_%s.npz" % name)
     np.savez_compressed(path, **out)
     print("%-26s steps=%5d accepts=%5d  -> %s (%d bytes)"
-          % (name, total, int(np.sum(out["accept"] > 0)), os.path.relpath(path, ROOT), os.path.getsize(path)))
+          % (name, total, int(np.sum(out["accept"] > 0)), path, os.path.getsize(path)))
 
 
 def seeded_anchors(me):
@@ -181,12 +187,50 @@ def seeded_anchors(me):
     np.savez_compressed(os.path.join(GOLDEN_DIR, "seeded_readme_1real.npz"), **rows)
 
 
-def main():
+def generate():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     me = import_reference()
     for i, (name, spec) in enumerate(sorted(scenarios.SCENARIOS.items())):
         run_scenario(me, name, spec, stream_seed=1000 + i)
     seeded_anchors(me)
+
+
+def check():
+    """Regenerate every fixture into a temporary directory and compare it, array by array and bit by bit, with the
+    committed one.  Returns the number of differing files."""
+    import tempfile
+    global GOLDEN_DIR
+    committed = GOLDEN_DIR
+    bad = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        GOLDEN_DIR = tmp
+        try:
+            generate()
+        finally:
+            GOLDEN_DIR = committed
+        for fname in sorted(os.listdir(tmp)):
+            new = np.load(os.path.join(tmp, fname))
+            path = os.path.join(committed, fname)
+            if not os.path.exists(path):
+                print("MISSING  %s" % fname)
+                bad += 1
+                continue
+            old = np.load(path)
+            diff = [k for k in new.files if k not in old.files or new[k].shape != old[k].shape
+                    or not np.array_equal(new[k], old[k], equal_nan=new[k].dtype.kind in "fc")]
+            diff += [k for k in old.files if k not in new.files]
+            print("%-8s %s%s" % ("DIFFERS" if diff else "same", fname, (": " + ", ".join(diff)) if diff else ""))
+            bad += bool(diff)
+    return bad
+
+
+def main():
+    if os.environ.get("PYTHONHASHSEED") != "0":
+        sys.exit("run with PYTHONHASHSEED=0 (the reference's energy-term column order follows the hash seed; see the "
+                 "module docstring)")
+    if "--check" in sys.argv[1:]:
+        sys.exit(1 if check() else 0)
+    generate()
 
 
 if __name__ == "__main__":

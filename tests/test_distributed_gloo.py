@@ -101,3 +101,85 @@ def test_pooled_factor_matches_per_chain_convention():
     k = (zc.T @ zc.conj()) / 200                       # E[z z^H]
     lc = np.array([[packed[3], 0], [packed[4] + 1j * packed[5], packed[6]]])
     assert np.allclose(lc @ lc.conj().T, np.conj(k))   # proposals use conj(K) (metropolis_engine.py:292-298)
+
+
+class _OracleEngine:
+    """Stand-in for MetropolisEngine on a GPU-less host: the attribute / method surface metropolisengine_amd.distributed
+    drives (pooled moments, their split begin/end form, the shared proposal factor), backed by an oracle shard."""
+
+    def __init__(self, shard, nr, nc, device=0):
+        self.shard, self.num_real_params, self.num_complex_params, self.device = shard, nr, nc, device
+        self.shared_factor, self._pending = None, None
+
+    def pooled_moments(self):
+        return self.shard.pooled_moments()
+
+    def pooled_moments_begin(self):
+        assert self._pending is None, "one reduction in flight per engine"
+        self._pending = self.shard.pooled_moments()      # the state at the time of _begin
+
+    def pooled_moments_end(self):
+        out, self._pending = self._pending, None
+        return out
+
+    def set_shared_factor(self, packed):
+        self.shared_factor = np.array(packed, dtype=np.float64)
+
+
+def _worker_surface(rank, world, port, n_total, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from metropolisengine_amd.distributed import (adapt_pooled_shape, pooled_statistics, pooled_statistics_begin,
+                                                  pooled_statistics_end, shard_chains)
+    from oracle import energies
+    from oracle.manychain import ManyChainOracle
+    offset, count = shard_chains(n_total, rank, world)
+    a = (1.0, 2.0)
+    shard = ManyChainOracle(2, 2, energies.diag_quadratic(2, 2, a, a), count, seed=5, temp=1.0, initial_real_params=[0.0, 0.0],
+                            initial_complex_params=[0j, 0j], chain_offset=offset, sampling_width=0.4)
+    eng = _OracleEngine(shard, 2, 2)
+    shard.step(60)
+    direct = pooled_statistics(eng)
+    pooled_statistics_begin(eng)
+    shard.step(5)                                   # work enqueued between _begin and _end does not change the result
+    split = pooled_statistics_end(eng)
+    assert np.array_equal(direct["covariance"], split["covariance"]) and direct["n_chains"] == split["n_chains"] == n_total
+    stats = adapt_pooled_shape(eng, jitter=1e-9)     # pool over ranks -> factor -> install
+    np.savez(os.path.join(out_dir, "surface%d.npz" % rank), factor=eng.shared_factor, cov=stats["covariance"],
+             n=stats["n_chains"], x=shard.x)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_pooled_statistics_surface(tmp_path):
+    """pooled_statistics, its begin/end form and adapt_pooled_shape at world size 2: every rank installs the SAME factor,
+    the Cholesky factor of the covariance pooled over both ranks' chains."""
+    from metropolisengine_amd.distributed import pooled_factor
+    n_total, world = 301, 2
+    mp.spawn(_worker_surface, args=(world, _free_port(), n_total, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "surface0.npz"), np.load(tmp_path / "surface1.npz")
+    assert int(r0["n"]) == int(r1["n"]) == n_total
+    assert np.array_equal(r0["factor"], r1["factor"]) and np.array_equal(r0["cov"], r1["cov"])
+    x = np.concatenate((r0["x"], r1["x"]))
+    cov = np.cov(x.T, bias=True)
+    assert np.allclose(r0["cov"], cov, atol=1e-12)
+    assert np.allclose(r0["factor"], pooled_factor(cov, 2, 2, jitter=1e-9), atol=1e-9)
+
+
+def test_rccl_path_refuses_a_device_mismatch(monkeypatch):
+    """The nccl branch of pooled_statistics allocates the all-reduce buffer on the ENGINE's GPU and refuses to run when
+    torch's current device is another one (a cross-device write would fault instead of raising)."""
+    from metropolisengine_amd import distributed
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "nccl")
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 1)
+
+    class _Engine:
+        num_real_params, num_complex_params, device = 2, 0, 0
+
+        def pooled_moments_into(self, ptr, n):
+            raise AssertionError("must not be reached")
+    with pytest.raises(RuntimeError, match="current device"):
+        distributed.pooled_statistics(_Engine())
