@@ -91,16 +91,23 @@ typedef enum me_field {
   ME_FIELD_COV = 4,      /* [P]  running covariance, packed: real block row-major lower triangle, then for
                                  each complex row i: (Re,Im) of K_ij for j<i, then K_ii */
   ME_FIELD_OBS_MEAN = 5, /* [2nr+nc] running mean of |x_r|, |z_c|, x_r^2 */
-  ME_FIELD_FACTOR = 6    /* [P]  Cholesky factors used by the proposals (same packing; conj(K) for complex) */
+  ME_FIELD_FACTOR = 6,   /* [P]  Cholesky factors used by the proposals (same packing; conj(K) for complex) */
+  ME_FIELD_ENERGY_TOTAL = 7 /* [1] ME_FLAG_REFERENCE_ENERGY_LEDGERS only: the separate `energy_total` that step_all of a
+                               mixed engine compares against and updates (metropolis_engine.py:252-255) */
 } me_field;
 
 /* me_config.flags */
 typedef enum me_flags {
-  ME_FLAG_TRACK_COVARIANCE = 1 /* parameter spaces whose per-chain matrix is too large for the factor kernels (more
+  ME_FLAG_TRACK_COVARIANCE = 1, /* parameter spaces whose per-chain matrix is too large for the factor kernels (more
                                   than 160 packed entries, e.g. 64 real parameters) keep means and observables only
                                   by default; with this flag measure() also maintains each chain's running covariance
                                   (metropolis_engine.py:416-427) as statistics -- P*4 bytes per chain, read and
                                   written once per measure().  Smaller spaces always track it. */
+  ME_FLAG_REFERENCE_ENERGY_LEDGERS = 2 /* reproduce the reference's TWO energy ledgers: step_all of a
+                                  mixed engine compares against and updates `energy_total` only (metropolis_engine.py:
+                                  252-255), group steps compare against and update `energy[term]` only (:214-221,
+                                  :230-237), so a driver that mixes both call styles decides on stale energies exactly
+                                  as the reference does.  Default: one coherent ledger per chain.  Mixed engines only. */
 } me_flags;
 
 typedef struct me_config {

@@ -14,10 +14,11 @@ ME_F32, ME_F64 = 0, 1
 (ENERGY_ISO_QUAD, ENERGY_DIAG_QUAD, ENERGY_DENSE_QUAD, ENERGY_LANDAU_TOY, ENERGY_CYLINDER, ENERGY_USER,
  ENERGY_USER_INDIRECT, ENERGY_LANDAU_TERMS) = range(8)
 FLAG_TRACK_COVARIANCE = 1
+FLAG_REFERENCE_ENERGY_LEDGERS = 2
 REJECT_NONE, REJECT_ABS_REAL0_GE, REJECT_USER = 0, 1, 2
 STEP_ALL, STEP_REAL_GROUP, STEP_COMPLEX_GROUP, STEP_COMPLEX_MAGNITUDE_PHASE = range(4)
 COV_REFERENCE, COV_FIXED, COV_POOLED = 0, 1, 2
-(FIELD_PARAMS, FIELD_ENERGY, FIELD_WIDTH, FIELD_MEAN, FIELD_COV, FIELD_OBS_MEAN, FIELD_FACTOR) = range(7)
+(FIELD_PARAMS, FIELD_ENERGY, FIELD_WIDTH, FIELD_MEAN, FIELD_COV, FIELD_OBS_MEAN, FIELD_FACTOR, FIELD_ENERGY_TOTAL) = range(8)
 
 _dp = ctypes.POINTER(ctypes.c_double)
 

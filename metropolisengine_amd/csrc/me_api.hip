@@ -124,6 +124,7 @@ struct me_engine {
   unsigned long long chain_offset = 0, seed = 0;
   double temp = 0, target_acceptance = 0.3, alpha = 0, ratio = 0, reject_bound = 0;
   int m = 0, energy_kind = 0, reject_kind = 0, cov_mode = 0;
+  bool stale_total = false;          // ME_FLAG_REFERENCE_ENERGY_LEDGERS on a mixed engine: ledger row n_terms = energy_total
   std::vector<double> shared_host;   // the packed factor last given to me_set_shared_factor (empty: none); checkpoints
   int cov_kind = CK_IDENTITY;
   int grid_blocks = 0;
@@ -200,6 +201,11 @@ int field_info(me_engine *e, int field, void **ptr, int *comps) {
                                            "kept on request only (me_config.flags: ME_FLAG_TRACK_COVARIANCE), and not "
                                            "at all where the field would pass 4 GiB");
       *ptr = e->cov; *comps = e->p; return ME_OK;
+    case ME_FIELD_ENERGY_TOTAL:
+      if (!e->stale_total)
+        return fail(e, ME_ERR_UNSUPPORTED, "this engine keeps one coherent energy ledger (sum ME_FIELD_ENERGY); a separate "
+                                           "energy_total exists with ME_FLAG_REFERENCE_ENERGY_LEDGERS only");
+      *ptr = (unsigned char *)e->energy + (size_t)e->n_terms * (size_t)e->n * e->esize; *comps = 1; return ME_OK;
     case ME_FIELD_FACTOR:
       if (!e->factor) return fail(e, ME_ERR_UNSUPPORTED, "this engine keeps no per-chain proposal factors (dimensions "
                                                          "without per-chain kernels, or a field beyond 4 GiB)");
@@ -257,6 +263,7 @@ void fill_step_launch(me_engine *e, StepLaunch &l, int n_sweeps) {
   l.inj_uniforms = nullptr;
   l.group = GROUP_ALL;
   l.split_widths = (e->width_rows == 3 && !e->widths_synced) ? 1 : 0;
+  l.stale_total = e->stale_total ? 1 : 0;
   l.cov = e->cov;
   l.accept_slots = e->accept_slots;
   l.status = e->status;
@@ -360,6 +367,10 @@ int me_create(const me_config *c, me_engine **out) {
   if (c->reject_kind == ME_REJECT_USER && !ks->has_user_reject)
     return fail(nullptr, ME_ERR_UNSUPPORTED,
                 "ME_REJECT_USER: this user-energy plugin defines no me_user_reject (#define ME_USER_HAS_REJECT in its source)");
+  if ((c->flags & ME_FLAG_REFERENCE_ENERGY_LEDGERS) && (c->n_real == 0 || c->n_complex == 0))
+    return fail(nullptr, ME_ERR_INVALID,
+                "ME_FLAG_REFERENCE_ENERGY_LEDGERS applies to mixed engines (real and complex parameters): only their "
+                "step_all keeps a separate energy_total (metropolis_engine.py:241-259)");
   if (c->cov_mode == ME_COV_REFERENCE && !ks->per_chain_cov)
     return fail(nullptr, ME_ERR_UNSUPPORTED,
                 "per-chain adaptive covariance is not compiled for these dimensions; use ME_COV_FIXED or ME_COV_POOLED");
@@ -432,7 +443,8 @@ int me_create(const me_config *c, me_engine **out) {
   e->own_stream = true;
   const size_t n = (size_t)e->n, es = e->esize;
   ME_CREATE_HIP(hipMalloc(&e->x, n * e->d * es));
-  ME_CREATE_HIP(hipMalloc(&e->energy, n * e->n_terms * es));
+  e->stale_total = (c->flags & ME_FLAG_REFERENCE_ENERGY_LEDGERS) != 0;
+  ME_CREATE_HIP(hipMalloc(&e->energy, n * (e->n_terms + (e->stale_total ? 1 : 0)) * es));
   e->width_rows = (e->nr > 0 && e->nc > 0) ? 3 : 1;
   ME_CREATE_HIP(hipMalloc(&e->width, n * e->width_rows * es));
   ME_CREATE_HIP(hipMalloc(&e->mean, n * e->d * es));
@@ -571,6 +583,7 @@ int me_recompute_energy(me_engine *e) {
   if (!e) return ME_ERR_INVALID;
   ME_HIP(e, hipSetDevice(e->device));
   EnergyLaunch l;
+  l.total_row = e->stale_total ? e->n_terms : -1;
   l.x = e->x;
   l.energy = e->energy;
   l.coef_device = e->coef_dev;

@@ -391,6 +391,7 @@ struct StepArgs {
   uint32_t seed_lo, seed_hi;
   int n_sweeps, reject_kind;
   int split_widths;   // mixed engines: group widths (rows 1, 2) differ from the shared width (row 0)
+  int stale_total;    // quirk Q5 mode: a mixed engine's step_all compares against / updates ledger row T only
   R reject_bound, temp, inv_temp, inv_temp_log2e, ratio, p, damping, up, down;
 };
 
@@ -436,7 +437,12 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   bool bad_energy = false, bad_width = false;
   const long long stride = (long long)gridDim.x * blockDim.x;   // 64 threads per block, or 256 for fused sweeps
   using Ledger = EnergyLedger<R, Energy, GROUP>;
-  const Field<R> fx(a.x, a.n, D), fe(a.energy, a.n, Ledger::T), fw(a.width, a.n, MIXED ? 3 : 1);
+  const Field<R> fx(a.x, a.n, D), fe(a.energy, a.n, Ledger::T + (MIXED ? 1 : 0)), fw(a.width, a.n, MIXED ? 3 : 1);
+  // The reference keeps TWO ledgers: step_all of a mixed engine decides against `energy_total` and
+  // updates only that (metropolis_engine.py:252-255); group steps use `energy[term]` (:214-221, :230-237).  With
+  // ME_FLAG_REFERENCE_ENERGY_LEDGERS the total lives in ledger row T and this kernel touches only the rows the
+  // reference's function touches; by default there is one coherent ledger.
+  const bool stale_total = MIXED && GROUP == GROUP_ALL && a.stale_total != 0;
   constexpr bool PER_CHAIN = CK == CK_PER_CHAIN || CK == CK_PER_CHAIN_NT;
   const Field<R> ffac(a.factor, a.n, PER_CHAIN ? NR * (NR + 1) / 2 + NC * NC : 0);
   for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < a.n; c += stride) {
@@ -445,7 +451,9 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
 #pragma unroll
     for (int d = 0; d < D; ++d) x[d] = fx.load(d, coff);
     Ledger ledger;
-    ledger.load(fe, coff);
+    R total_q5 = R(0);
+    if (stale_total) total_q5 = fe.load(Ledger::T, coff);
+    else ledger.load(fe, coff);
     // w: the width this launch adapts; w_r / w_c: the widths the real / complex proposals use
     R w = fw.load(MIXED ? GROUP : 0, coff);
     R w_r = w, w_c = w;
@@ -549,7 +557,7 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
       else if (a.reject_kind == ME_REJECT_USER) rejected = energy_reject(en, xp, 0);
       R terms_new[Ledger::T];
       const R e_new = ledger.propose(en, xp, terms_new);
-      const R diff = e_new - ledger.partial();
+      const R diff = e_new - (stale_total ? total_q5 : ledger.partial());
       bool accept = diff <= R(0);
       if (a.temp > R(0)) accept = accept || N_::uphill(u, diff, a.inv_temp, a.inv_temp_log2e);
       accept = accept && !rejected;
@@ -573,7 +581,8 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
 #pragma unroll
         for (int d = 0; d < D; ++d) x[d] = accept ? xp[d] : x[d];
       }
-      ledger.commit(accept, terms_new);
+      if (stale_total) total_q5 = accept ? e_new : total_q5;
+      else ledger.commit(accept, terms_new);
       // ---- Robbins-Monro width update (:429-456); step_all of a mixed engine mirrors it into both groups (:436-437)
       w = N_::adapt(w, accept, a.ratio, a.p, a.damping, a.up, a.down);
       if constexpr (GROUP == GROUP_ALL) w_r = w_c = w;
@@ -584,7 +593,8 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
     bad_width |= !(w > R(0));
 #pragma unroll
     for (int d = 0; d < D; ++d) fx.store(d, coff, x[d]);
-    ledger.store(fe, coff);
+    if (stale_total) fe.store(Ledger::T, coff, total_q5);
+    else ledger.store(fe, coff);
     fw.store(MIXED ? GROUP : 0, coff, w);   // after a mixed step_all rows 1, 2 are implied equal to row 0 (host flag)
   }
   // acceptance tracking: ballot + popcount per sweep, then ONE plain read-modify-write of the wavefront's own
@@ -600,7 +610,7 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
 
 template <typename R, int NR, int NC, class Energy>
 __global__ void __launch_bounds__(kStepThreads) k_init_energy(const R *xs, R *energy, long long n, unsigned int *status,
-                                                                Energy en) {
+                                                                Energy en, int total_row) {
   constexpr int D = NR + 2 * NC;
   const long long stride = (long long)gridDim.x * kStepThreads;
   for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < n; c += stride) {
@@ -609,14 +619,17 @@ __global__ void __launch_bounds__(kStepThreads) k_init_energy(const R *xs, R *en
     for (int d = 0; d < D; ++d) x[d] = xs[(long long)d * n + c];
     constexpr int T = term_count<Energy>::value;   // every term of the ledger (initialize_energy_dict, :152-155)
     bool finite = true;
+    R total = R(0);
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       R e;
       if constexpr (T == 1) e = en(x);
       else e = en.term(t, x);
       energy[(long long)t * n + c] = e;
+      total = t == 0 ? e : total + e;
       finite = finite && Num<R>::finite(e);
     }
+    if (total_row >= 0) energy[(long long)total_row * n + c] = total;   // the reference's energy_total (:125)
     if (!finite) atomicOr(status, (unsigned int)ST_NONFINITE_ENERGY);
   }
 }

@@ -61,6 +61,7 @@ struct StepLaunch {
   int n_sweeps, energy_kind, cov_kind, reject_kind, grid_blocks;
   int group;          // StepGroup: 0 = all (step_all), 1 = real group, 2 = complex group (mixed engines)
   int split_widths;   // mixed engines: rows 1, 2 of the width field differ from row 0
+  int stale_total;    // ME_FLAG_REFERENCE_ENERGY_LEDGERS: step_all of a mixed engine uses the extra ledger row only
   const void *cov;    // per-chain covariance field (magnitude-phase sampler reads its diagonal)
   double reject_bound, temp, ratio, target_acceptance, damping;
 };
@@ -77,6 +78,7 @@ struct MeasureLaunch {
 };
 
 struct EnergyLaunch {
+  int total_row;      // >= 0: also write the sum of the terms into this ledger row (the reference's energy_total)
   void *x, *energy;
   const void *coef_device;
   const double *coef_host;

@@ -140,6 +140,7 @@ StepArgs<R> typed(const StepLaunch &l) {
   a.n_sweeps = l.n_sweeps;
   a.reject_kind = l.reject_kind;
   a.split_widths = l.split_widths;
+  a.stale_total = l.stale_total;
   a.reject_bound = (R)l.reject_bound;
   a.temp = (R)l.temp;
   a.inv_temp = l.temp > 0 ? (R)(1.0 / l.temp) : (R)0;
@@ -343,7 +344,7 @@ hipError_t init_energy(const EnergyLaunch &l, hipStream_t stream) {
   return with_energy<R>(l.energy_kind, l.coef_host, l.n_coef, l.coef_device, [&](const auto &en) {
     using Energy = std::decay_t<decltype(en)>;
     hipLaunchKernelGGL((k_init_energy<R, NR, NC, Energy>), dim3(grid_for(l.n, l.grid_blocks)), dim3(kStepThreads), 0,
-                       stream, (const R *)l.x, (R *)l.energy, l.n, l.status, en);
+                       stream, (const R *)l.x, (R *)l.energy, l.n, l.status, en, l.total_row);
     return hipGetLastError();
   });
 }

@@ -9,7 +9,8 @@ marshals arguments and unpacks results.  Differences from the reference, all for
    ``reject_condition`` is a :class:`~metropolisengine_amd.energy.RejectSpec`.  (The reference silently drops a
    ``reject_condition`` given to the constructor -- SURVEY.md quirk Q6; here it is honoured.)
  * keyword-only extras: ``n_chains``, ``seed``, ``dtype``, ``device``, ``chain_offset``, ``cov_mode``, ``trace_chains``,
-   ``trace_stride``, ``track_covariance``.
+   ``trace_stride``, ``track_covariance``, ``reference_energy_ledgers`` (reproduce the reference's two energy ledgers,
+   SURVEY.md quirk Q5: ``step_all`` of a mixed engine uses ``energy_total``, group steps ``energy[term]``).
  * with ``n_chains == 1`` attributes have the reference's shapes and ``step_all()`` returns a bool; with more
    chains they gain a leading chain axis and ``step_all()`` returns ``None`` (it stays asynchronous).
  * randomness is a seeded counter-based Philox stream per global chain id instead of numpy's global state.
@@ -73,7 +74,8 @@ class MetropolisEngine:
                  initial_complex_params=None, sampling_width=0.05, covariance_matrix_real=None,
                  covariance_matrix_complex=None, params_names=None, target_acceptance=.3, temp=0,
                  complex_sample_method="multivariate-gaussian", *, n_chains=1, seed=0, dtype="f32", device=0,
-                 chain_offset=0, cov_mode="reference", trace_chains=None, trace_stride=1, track_covariance=False):
+                 chain_offset=0, cov_mode="reference", trace_chains=None, trace_stride=1, track_covariance=False,
+                 reference_energy_ledgers=False):
         if initial_real_params is None and initial_complex_params is None:
             print("must give list containing  at least one value for initial real or complex parameters")
             raise ValueError("no initial parameters")                                    # metropolis_engine.py:37-39
@@ -145,7 +147,9 @@ class MetropolisEngine:
         self.cov_mode = cov_mode
         # parameter spaces beyond the factor kernels (> 160 packed matrix entries, e.g. 64 real parameters) keep the
         # per-chain running covariance only on request: P floats per chain, read and written once per measure()
-        cfg.flags = _capi.FLAG_TRACK_COVARIANCE if track_covariance else 0
+        self.reference_energy_ledgers = bool(reference_energy_ledgers)
+        cfg.flags = ((_capi.FLAG_TRACK_COVARIANCE if track_covariance else 0) |
+                     (_capi.FLAG_REFERENCE_ENERGY_LEDGERS if reference_energy_ledgers else 0))
         cfg.temp = float(temp)
         cfg.target_acceptance = float(target_acceptance)
         cfg.sampling_width = float(sampling_width)
@@ -370,7 +374,10 @@ class MetropolisEngine:
 
     @property
     def energy_total(self):
-        e = self._get(_capi.FIELD_ENERGY).sum(axis=1)     # sum of the ledger's terms (:158-162)
+        if self.reference_energy_ledgers:                  # the reference's separate attribute (quirk Q5)
+            e = self._get(_capi.FIELD_ENERGY_TOTAL)[:, 0]
+        else:
+            e = self._get(_capi.FIELD_ENERGY).sum(axis=1)     # sum of the ledger's terms (:158-162)
         return float(e[0]) if self.n_chains == 1 else e
 
     @property
@@ -461,7 +468,7 @@ class MetropolisEngine:
     # constructor warm start, metropolis_engine.py:17,24)
     _STATE_FIELDS = (("params", _capi.FIELD_PARAMS), ("energy", _capi.FIELD_ENERGY), ("width", _capi.FIELD_WIDTH),
                      ("mean", _capi.FIELD_MEAN), ("obs_mean", _capi.FIELD_OBS_MEAN), ("cov", _capi.FIELD_COV),
-                     ("factor", _capi.FIELD_FACTOR))
+                     ("factor", _capi.FIELD_FACTOR), ("energy_total", _capi.FIELD_ENERGY_TOTAL))
 
     def state_dict(self):
         state = {}

@@ -4,10 +4,11 @@ group, metropolis_engine.py:209-239 called directly) and the magnitude-phase com
 float64 engines follow the many-chain oracle on identical Philox streams (1e-9) and replay the reference's own golden
 trajectories through me_step_injected; float32 engines are checked statistically.
 
-Known deviation, by design: a driver that MIXES step_all() with group steps on one mixed engine makes the reference
-compare against stale energies (step_all keeps ``energy_total``, group steps keep ``energy[term]``: SURVEY.md quirk Q5);
-the GPU engine keeps one coherent energy per chain, so the golden scenario ``groups_2real_2complex`` is replayed on the
-CPU restatement only.
+A driver that MIXES step_all() with group steps on one mixed engine makes the reference compare against stale energies
+(step_all keeps ``energy_total``, group steps keep ``energy[term]``: SURVEY.md quirk Q5).  By default the GPU engine
+keeps one coherent energy per chain; with ``reference_energy_ledgers=True`` (ME_FLAG_REFERENCE_ENERGY_LEDGERS) it keeps
+the reference's two ledgers, and the golden scenario ``groups_2real_2complex`` -- which mixes both call styles -- is
+replayed through the HIP kernels like the others (test_reference_golden_mixed_call_styles_stale_ledgers).
 """
 import os
 
@@ -83,6 +84,17 @@ def test_f64_step_kinds_follow_the_oracle(name):
     assert eng.accept_stats() == (ora.accepted, ora.proposed)
 
 
+# oracle/scenarios.py:_coupled as a dense quadratic form over [x0, x1, Re z0, Re z1, Im z0, Im z1]
+_COUPLED = np.zeros((6, 6))
+_COUPLED[0, 0], _COUPLED[1, 1] = 1.0, 2.0
+_COUPLED[0, 1] = _COUPLED[1, 0] = 0.3
+_COUPLED[2, 2] = _COUPLED[4, 4] = 1.5
+_COUPLED[3, 3] = _COUPLED[5, 5] = 3.0
+_COUPLED[2, 3] = _COUPLED[3, 2] = 0.4
+_COUPLED[4, 5] = _COUPLED[5, 4] = 0.4
+_COUPLED[4, 3] = _COUPLED[3, 4] = 0.7
+_COUPLED[2, 5] = _COUPLED[5, 2] = -0.7
+
 GOLDEN = {
     "groups_landau_terms": (me.LandauToy(1.0, -1.0, 0.5), "multivariate-gaussian"),
     "magphase_1real_2complex": (me.DiagQuadratic((0.5,), (1.0, 3.0)), "magnitude-phase"),
@@ -121,6 +133,40 @@ def test_reference_golden_step_kinds_on_gpu(name, golden_dir):
             assert np.allclose(eng.covariance_matrix_real, gold["cov_real"][k], rtol=0, atol=TOL)
         assert np.allclose(eng.covariance_matrix_complex, gold["cov_complex"][k], rtol=0, atol=TOL)
         assert np.allclose(eng.observables_mean, gold["observables_mean"][k], rtol=0, atol=TOL)
+
+
+def test_reference_golden_mixed_call_styles_stale_ledgers(golden_dir):
+    """groups_2real_2complex: (real group, complex group, step_all, real group, measure) x 120 recorded from the reference.
+    Its step_all decides against `energy_total`, which the group steps never update, and its group steps against
+    `energy[term]`, which step_all never updates (metropolis_engine.py:252-255, :214-221, :230-237): every decision,
+    both ledgers, widths and running statistics are reproduced with reference_energy_ledgers=True."""
+    name = "groups_2real_2complex"
+    spec = scenarios.SCENARIOS[name]
+    gold = np.load(os.path.join(golden_dir, "traj_%s.npz" % name))
+    nr, nc = scenarios.dims(spec)
+    eng = me.MetropolisEngine(me.DenseQuadratic(_COUPLED), None, spec["real"], spec["cplx"], temp=spec["temp"], n_chains=1,
+                              dtype="f64", reference_energy_ledgers=True)
+    t, stale_seen = 0, False
+    for k in range(spec["n_measures"]):
+        for op in scenarios.ops(spec)[:-1]:
+            kind = {"all": _capi.STEP_ALL, "real": _capi.STEP_REAL_GROUP, "complex": _capi.STEP_COMPLEX_GROUP}[op]
+            eng.step_injected(gold["normals"][t:t + 1, None, :], gold["uniforms"][t:t + 1, :1], kind=kind)
+            assert np.allclose(eng.real_params, gold["real_params"][t], rtol=0, atol=TOL), (t, op)
+            assert np.allclose(eng.complex_params, gold["complex_params"][t], rtol=0, atol=TOL), (t, op)
+            assert abs(eng.real_group_sampling_width - gold["real_width"][t]) < TOL
+            assert abs(eng.complex_group_sampling_width - gold["complex_width"][t]) < TOL
+            assert abs(eng.energy_total - gold["energy_total"][t]) < TOL, (t, op)
+            assert abs(eng.energy["total"] - gold["energy_terms"][t, 0]) < TOL, (t, op)
+            stale_seen |= abs(gold["energy_total"][t] - gold["energy_terms"][t, 0]) > 1e-6
+            t += 1
+        eng.measure()
+        assert np.allclose(eng.real_mean, gold["real_mean"][k], rtol=0, atol=TOL)
+        assert np.allclose(eng.covariance_matrix_real, gold["cov_real"][k], rtol=0, atol=TOL)
+        assert np.allclose(eng.covariance_matrix_complex, gold["cov_complex"][k], rtol=0, atol=TOL)
+    assert stale_seen                      # the scenario really exercises the quirk
+    # pure engines have no separate step_all ledger: the flag is refused there
+    with pytest.raises(ValueError):
+        me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0, 0.0], None, temp=1.0, n_chains=4, reference_energy_ledgers=True)
 
 
 def test_f32_group_stepping_is_a_valid_sampler():
