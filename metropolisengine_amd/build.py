@@ -92,7 +92,7 @@ def build(force=False, jobs=None, verbose=True):
     for nr, nc, dense, per_chain in KERNEL_DIMS:
         units.append((os.path.join(OBJ_DIR, "me_kernels_%d_%d.o" % (nr, nc)), os.path.join(CSRC, "me_kernels.hip"),
                       ["-DME_NR=%d" % nr, "-DME_NC=%d" % nc, "-DME_DENSE=%d" % dense, "-DME_PER_CHAIN=%d" % per_chain]))
-    for name in ("me_generic", "me_statistics", "me_api"):
+    for name in ("me_generic", "me_statistics", "me_runtime_dims", "me_api"):
         units.append((os.path.join(OBJ_DIR, name + ".o"), os.path.join(CSRC, name + ".hip"), []))
 
     todo = []
@@ -177,8 +177,9 @@ def build_dims(n_real, n_complex, force=False):
     d = n_real + 2 * n_complex
     packed = n_real * (n_real + 1) // 2 + n_complex * n_complex
     if d > MAX_REGISTER_DOF:
-        raise RuntimeError("register-resident kernels support at most %d real degrees of freedom (got %d)"
-                           % (MAX_REGISTER_DOF, d))
+        raise RuntimeError("register-resident kernels support at most %d real degrees of freedom (got %d); larger spaces "
+                           "run on the runtime-dimension kernels of the main library (csrc/me_runtime_dims.hip), no build "
+                           "needed" % (MAX_REGISTER_DOF, d))
     defines = ["-DME_NR=%d" % n_real, "-DME_NC=%d" % n_complex, "-DME_DENSE=%d" % int(d <= 24),
                "-DME_PER_CHAIN=%d" % int(packed <= MAX_PACKED_IN_REGISTERS)]
     return _build_plugin(dims_plugin_path(n_real, n_complex), defines, [], force=force)

@@ -40,9 +40,14 @@ const KernelSet *find_kernel_set(int dtype, int n_real, int n_complex, int energ
     }
     return s;
   }
+  // beyond the register-resident kernels: the runtime-dimension set (any dimensions, separable energies)
+  if (n_real + 2 * n_complex > kMaxRegisterDof && !is_user_kind(energy_kind))
+    for (const KernelSet *s : registry())
+      if (s->dtype == dtype && s->n_real < 0 && s->has_energy(energy_kind)) return s;
   return nullptr;
 }
 bool has_dims(int dtype, int n_real, int n_complex) {
+  if (n_real + 2 * n_complex > kMaxRegisterDof) return true;
   std::lock_guard<std::mutex> lock(registry_mutex());
   for (const KernelSet *s : registry())
     if (s->dtype == dtype && s->n_real == n_real && s->n_complex == n_complex && !s->user_name) return true;
@@ -249,6 +254,8 @@ int upload_shared_factor(me_engine *e, const double *packed) {
 }
 
 void fill_step_launch(me_engine *e, StepLaunch &l, int n_sweeps) {
+  l.n_real = e->nr;
+  l.n_complex = e->nc;
   l.x = e->x;
   l.energy = e->energy;
   l.width = e->width;
@@ -367,6 +374,17 @@ int me_create(const me_config *c, me_engine **out) {
   if (c->reject_kind == ME_REJECT_USER && !ks->has_user_reject)
     return fail(nullptr, ME_ERR_UNSUPPORTED,
                 "ME_REJECT_USER: this user-energy plugin defines no me_user_reject (#define ME_USER_HAS_REJECT in its source)");
+  if (ks->n_real < 0) {   // the runtime-dimension kernel set (me_runtime_dims.hip)
+    if (c->cov_mode != ME_COV_FIXED)
+      return fail(nullptr, ME_ERR_UNSUPPORTED,
+                  "parameter spaces beyond " + std::to_string(kMaxRegisterDof) + " real degrees of freedom run with the "
+                  "identity proposal shape only: use ME_COV_FIXED (cov_mode=\"fixed\"); the ensemble covariance comes from "
+                  "me_pooled_moments");
+    if (c->flags & ME_FLAG_REFERENCE_ENERGY_LEDGERS)
+      return fail(nullptr, ME_ERR_UNSUPPORTED, "ME_FLAG_REFERENCE_ENERGY_LEDGERS is not available beyond " +
+                                                   std::to_string(kMaxRegisterDof) + " real degrees of freedom");
+    if (c->reject_kind == ME_REJECT_USER) return fail(nullptr, ME_ERR_UNSUPPORTED, "no user plugins at these dimensions");
+  }
   if ((c->flags & ME_FLAG_REFERENCE_ENERGY_LEDGERS) && (c->n_real == 0 || c->n_complex == 0))
     return fail(nullptr, ME_ERR_INVALID,
                 "ME_FLAG_REFERENCE_ENERGY_LEDGERS applies to mixed engines (real and complex parameters): only their "
@@ -469,6 +487,21 @@ int me_create(const me_config *c, me_engine **out) {
                               (size_t)(1 + e->d + e->nr + e->nc + e->d * (e->d + 1) / 2)));
   ME_CREATE_HIP(hipMemsetAsync(e->accept_slots, 0, (size_t)e->n_slots * sizeof(unsigned long long), e->stream));
   ME_CREATE_HIP(hipMemsetAsync(e->status, 0, sizeof(unsigned int), e->stream));
+  if (ks->n_real < 0 && e->energy_kind == ME_ENERGY_DIAG_QUAD) {
+    // the runtime-dimension kernels read one weight per real degree of freedom: a_i, then b_j for Re z_j and again for Im z_j
+    if ((int)e->coef.size() != e->nr + e->nc) {
+      g_create_error = "wrong number of energy coefficients for this energy kind";
+      release(e);
+      return ME_ERR_INVALID;
+    }
+    std::vector<double> expanded(e->coef.begin(), e->coef.begin() + e->nr);
+    expanded.insert(expanded.end(), e->coef.begin() + e->nr, e->coef.end());
+    expanded.insert(expanded.end(), e->coef.begin() + e->nr, e->coef.end());
+    std::vector<unsigned char> bytes;
+    to_device_type(expanded.data(), expanded.size(), e->dtype, bytes);
+    ME_CREATE_HIP(hipMalloc(&e->coef_dev, bytes.size()));
+    ME_CREATE_HIP(hipMemcpy(e->coef_dev, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+  }
   if (e->energy_kind == ME_ENERGY_DENSE_QUAD || (is_user_kind(e->energy_kind) && !e->coef.empty())) {
     std::vector<unsigned char> bytes;
     to_device_type(e->coef.data(), e->coef.size(), e->dtype, bytes);
@@ -583,6 +616,8 @@ int me_recompute_energy(me_engine *e) {
   if (!e) return ME_ERR_INVALID;
   ME_HIP(e, hipSetDevice(e->device));
   EnergyLaunch l;
+  l.n_real = e->nr;
+  l.n_complex = e->nc;
   l.total_row = e->stale_total ? e->n_terms : -1;
   l.x = e->x;
   l.energy = e->energy;
@@ -705,6 +740,8 @@ int me_measure(me_engine *e) {
   ME_HIP(e, hipSetDevice(e->device));
   const unsigned long long count = e->measure_count + 1;   // metropolis_engine.py:343; committed once the launch succeeded
   MeasureLaunch l;
+  l.n_real = e->nr;
+  l.n_complex = e->nc;
   l.x = e->x;
   l.width = e->width;
   l.mean = e->mean;

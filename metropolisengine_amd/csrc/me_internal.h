@@ -44,6 +44,7 @@ constexpr int kFusedSweepsThreshold = 4;
 
 // Type-erased launch descriptors; scalars are doubles and are narrowed by the typed launcher.
 struct StepLaunch {
+  int n_real, n_complex;     // for the runtime-dimension kernel set (compile-time constants everywhere else)
   void *x, *energy, *width;
   const void *factor;        // CK_PER_CHAIN: [P][N]; CK_SHARED: [P]
   const void *factor_full;   // CK_SHARED on pure-real engines: the same factor as a dense [nr][nr] row-major matrix
@@ -67,6 +68,7 @@ struct StepLaunch {
 };
 
 struct MeasureLaunch {
+  int n_real, n_complex;
   void *x, *width, *mean, *cov, *obs_mean, *factor;
   unsigned int *status;
   long long n;
@@ -78,6 +80,7 @@ struct MeasureLaunch {
 };
 
 struct EnergyLaunch {
+  int n_real, n_complex;
   int total_row;      // >= 0: also write the sum of the terms into this ledger row (the reference's energy_total)
   void *x, *energy;
   const void *coef_device;
@@ -87,6 +90,10 @@ struct EnergyLaunch {
   long long n;
   int energy_kind, grid_blocks;
 };
+
+// largest n_real + 2 n_complex of the register-resident kernel sets (build.py: MAX_REGISTER_DOF); beyond it
+// find_kernel_set falls back to the runtime-dimension set (me_runtime_dims.hip), registered with n_real = n_complex = -1
+constexpr int kMaxRegisterDof = 96;
 
 struct KernelSet {
   const char *user_name;  // nullptr for the built-in sets; the plugin's name for user-energy sets

@@ -1,0 +1,283 @@
+// Runtime-dimension kernel set: parameter spaces beyond what the register-resident kernels are built for
+// (n_real + 2 n_complex > 96).  The reference has no limit on the number of parameters (metropolis_engine.py:41-60);
+// the compile-time-dimension kernels of me_device.h keep a chain's whole state in registers and stop at 96 real degrees of
+// freedom.  Here the dimensions are launch arguments and the state STREAMS:
+//
+//   k_step_runtime   pass 1: for each coordinate d -- load x_d, draw its normal, form x'_d = x_d + sigma g_d, add its term to
+//                    the proposed energy.  Nothing is stored.  Then wall, accept rule, width adaptation (:247-259,
+//                    :319-338, :429-456).  Pass 2, only if some lane of the wavefront accepted: the normals are drawn AGAIN
+//                    (Philox is counter-based, so "again" is a handful of integer instructions, not a stored array) and
+//                    the accepted lanes write x_d + sigma g_d.  A sweep therefore reads the state once (twice for
+//                    accepted chains, from cache) and writes only what changed -- less traffic than a register-resident
+//                    sweep, paid for with drawing the normals twice.
+//   k_measure_runtime, k_init_energy_runtime: the same loops over d for the running means / observables / energy.
+//
+// Supported: separable energies (ME_ENERGY_ISO_QUAD, ME_ENERGY_DIAG_QUAD), the identity proposal shape (ME_COV_FIXED),
+// the built-in wall, step_all and group-wise steps of mixed engines.  The word layout of a step is the one of every
+// other kernel (oracle/philox.py): normal i belongs to coordinate i, word 2 ceil(D/2) is the accept uniform.
+#include <type_traits>
+
+#include "me_device.h"
+
+namespace me {
+namespace {
+
+template <typename R>
+struct RuntimeStep {
+  int nr, nc, group, energy_kind;
+  R iso;                 // ME_ENERGY_ISO_QUAD: a
+  const R *weights;      // ME_ENERGY_DIAG_QUAD: D weights (real, then the complex weights twice), device memory
+};
+
+// one explicit fma in both passes: the state written by pass 2 is bit for bit the x' whose energy pass 1 summed
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+template <typename R>
+__device__ __forceinline__ R weight_of(const RuntimeStep<R> &p, int d) {
+  return p.energy_kind == ME_ENERGY_ISO_QUAD ? p.iso : p.weights[d];
+}
+
+template <typename R>
+__global__ void __launch_bounds__(kBlockThreads) k_step_runtime(StepArgs<R> a, RuntimeStep<R> p) {
+  using N_ = Num<R>;
+  N_::prepare();
+  const int nr = p.nr, nc = p.nc, D = nr + 2 * nc;
+  const int NW = 2 * ((D + 1) / 2);                 // words consumed by the Box-Muller pairs
+  const bool mixed = nr > 0 && nc > 0;
+  const int d0 = p.group == GROUP_COMPLEX ? nr : 0, d1 = p.group == GROUP_REAL ? nr : D;   // coordinates that move
+  unsigned int wave_accepted = 0;
+  bool bad_energy = false, bad_width = false;
+  const long long stride = (long long)gridDim.x * kBlockThreads, n = a.n;
+  for (long long c = (long long)blockIdx.x * kBlockThreads + threadIdx.x; c < n; c += stride) {
+    R *xc = a.x + c;
+    R e = a.energy[c];
+    const int wrow = mixed ? p.group : 0;
+    R w = a.width[(long long)wrow * n + c];
+    R w_r = w, w_c = w;
+    if (mixed && p.group == GROUP_ALL && a.split_widths) {
+      w_r = a.width[(long long)GROUP_REAL * n + c];
+      w_c = a.width[(long long)GROUP_COMPLEX * n + c];
+    }
+    const unsigned long long gid = a.chain_offset + (unsigned long long)c;
+    for (int s = 0; s < a.n_sweeps; ++s) {
+      const unsigned long long step = a.step_index + (unsigned long long)s;
+      auto block_of = [&](int b) {
+        U4 ctr;
+        ctr.x = (uint32_t)gid;
+        ctr.y = (uint32_t)(gid >> 32);
+        ctr.z = (uint32_t)step;
+        ctr.w = ((uint32_t)(step >> 32) << 16) | (uint32_t)b;
+        return philox4x32_10(ctr, a.seed_lo, a.seed_hi);
+      };
+      const R s_r = w_r, s_c = w_c * R(0.70710678118654752440);
+      // ---- pass 1: proposed energy (and the proposed x_0 for the wall)
+      R e_new = R(0), xp0 = R(0);
+      for (int b = 0; 4 * b < NW; ++b) {
+        const U4 o = block_of(b);
+        R g[4];
+        N_::normal_pair(o.x, o.y, g[0], g[1]);
+        N_::normal_pair(o.z, o.w, g[2], g[3]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int d = 4 * b + t;
+          if (d < D) {
+            const R xd = xc[(long long)d * n];
+            const bool moves = d >= d0 && d < d1;
+            const R xpd = moves ? fma_(d < nr ? s_r : s_c, g[t], xd) : xd;
+            e_new += weight_of(p, d) * xpd * xpd;
+            if (d == 0) xp0 = xpd;
+          }
+        }
+      }
+      const U4 ow = block_of(NW >> 2);
+      const uint32_t uword = (NW & 3) == 0 ? ow.x : ow.z;      // word NW is output NW % 4 (0 or 2) of block NW / 4
+      const R u = N_::unit(uword);
+      bool rejected = false;
+      if (a.reject_kind == ME_REJECT_ABS_REAL0_GE) rejected = !(N_::abs_(xp0) < a.reject_bound);
+      const R diff = e_new - e;
+      bool accept = diff <= R(0);
+      if (a.temp > R(0)) accept = accept || N_::uphill(u, diff, a.inv_temp, a.inv_temp_log2e);
+      accept = accept && !rejected;
+      bad_energy |= (!rejected && !N_::finite(e_new));
+      // ---- pass 2: the same normals again, accepted lanes commit
+      if (__ballot(accept)) {
+        for (int b = 0; 4 * b < NW; ++b) {
+          if (4 * b + 3 < d0 || 4 * b >= d1) continue;         // no moving coordinate in this block
+          const U4 o = block_of(b);
+          R g[4];
+          N_::normal_pair(o.x, o.y, g[0], g[1]);
+          N_::normal_pair(o.z, o.w, g[2], g[3]);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int d = 4 * b + t;
+            if (accept && d >= d0 && d < d1) xc[(long long)d * n] = fma_(d < nr ? s_r : s_c, g[t], xc[(long long)d * n]);
+          }
+        }
+      }
+      e = accept ? e_new : e;
+      w = N_::adapt(w, accept, a.ratio, a.p, a.damping, a.up, a.down);
+      if (p.group == GROUP_ALL) w_r = w_c = w;
+      else if (p.group == GROUP_REAL) w_r = w;
+      else w_c = w;
+      wave_accepted += (unsigned int)__popcll(__ballot(accept));
+    }
+    bad_width |= !(w > R(0));
+    a.energy[c] = e;
+    a.width[(long long)wrow * n + c] = w;
+  }
+  if ((threadIdx.x & 63) == 0 && wave_accepted) {
+    unsigned long long *slot = a.accept_slots + (size_t)blockIdx.x * (kBlockThreads >> 6) + (threadIdx.x >> 6);
+    *slot += (unsigned long long)wave_accepted;
+  }
+  const unsigned int bits = (bad_energy ? ST_NONFINITE_ENERGY : 0u) | (bad_width ? ST_BAD_WIDTH : 0u);
+  if (bits) atomicOr(a.status, bits);
+}
+
+template <typename R>
+__global__ void __launch_bounds__(kBlockThreads) k_measure_runtime(MeasureArgs<R> a, int nr, int nc) {
+  using N_ = Num<R>;
+  const int D = nr + 2 * nc, nobs = 2 * nr + nc;
+  const long long stride = (long long)gridDim.x * kBlockThreads, n = a.n;
+  for (long long c = (long long)blockIdx.x * kBlockThreads + threadIdx.x; c < n; c += stride) {
+    for (int d = 0; d < D; ++d) {                                                          // :404-410
+      const long long i = (long long)d * n + c;
+      a.mean[i] = a.mean[i] * a.keep + a.x[i] * a.inv_i;
+    }
+    for (int k = 0; k < nobs; ++k) {                                                       // :458-463, :412-414
+      R o;
+      if (k < nr) o = N_::abs_(a.x[(long long)k * n + c]);
+      else if (k < nr + nc) {
+        const R re = a.x[(long long)k * n + c], im = a.x[(long long)(k + nc) * n + c];
+        o = N_::sqrt_(re * re + im * im);
+      } else {
+        const R v = a.x[(long long)(k - nr - nc) * n + c];
+        o = v * v;
+      }
+      const long long i = (long long)k * n + c;
+      a.obs_mean[i] = a.obs_mean[i] * a.keep + o * a.inv_i;
+    }
+  }
+}
+
+template <typename R>
+__global__ void __launch_bounds__(kBlockThreads) k_init_energy_runtime(const R *x, R *energy, long long n, unsigned int *status,
+                                                                        RuntimeStep<R> p) {
+  const int D = p.nr + 2 * p.nc;
+  const long long stride = (long long)gridDim.x * kBlockThreads;
+  for (long long c = (long long)blockIdx.x * kBlockThreads + threadIdx.x; c < n; c += stride) {
+    R e = R(0);
+    for (int d = 0; d < D; ++d) {
+      const R v = x[(long long)d * n + c];
+      e += weight_of(p, d) * v * v;
+    }
+    energy[c] = e;
+    if (!Num<R>::finite(e)) atomicOr(status, (unsigned int)ST_NONFINITE_ENERGY);
+  }
+}
+
+bool has_energy(int kind) { return kind == ME_ENERGY_ISO_QUAD || kind == ME_ENERGY_DIAG_QUAD; }
+int energy_terms(int kind) { return has_energy(kind) ? 1 : 0; }
+
+template <typename R>
+bool fill(RuntimeStep<R> &p, int nr, int nc, int group, int kind, const double *coef, int n_coef, const void *coef_device) {
+  p.nr = nr;
+  p.nc = nc;
+  p.group = group;
+  p.energy_kind = kind;
+  p.iso = R(0);
+  p.weights = nullptr;
+  if (kind == ME_ENERGY_ISO_QUAD) {
+    if (n_coef != 1) return false;
+    p.iso = (R)coef[0];
+    return true;
+  }
+  if (kind == ME_ENERGY_DIAG_QUAD) {
+    if (n_coef != nr + nc || !coef_device) return false;
+    p.weights = (const R *)coef_device;        // expanded to D entries by me_create (me_api.hip)
+    return true;
+  }
+  return false;
+}
+
+int grid_of(long long n, int requested) {
+  long long blocks = (n + kBlockThreads - 1) / kBlockThreads;
+  if (requested > 0 && blocks > requested) blocks = requested;
+  return (int)(blocks < 1 ? 1 : blocks);
+}
+
+template <typename R>
+hipError_t step(const StepLaunch &l, hipStream_t stream) {
+  if (l.inj_normals) return hipErrorNotSupported;
+  if (l.cov_kind != CK_IDENTITY) return hipErrorNotSupported;
+  const bool mixed = l.n_real > 0 && l.n_complex > 0;
+  if (l.group != GROUP_ALL && !mixed) return hipErrorInvalidValue;
+  RuntimeStep<R> p;
+  if (!fill(p, l.n_real, l.n_complex, l.group, l.energy_kind, l.coef_host, l.n_coef, l.coef_device)) return hipErrorInvalidValue;
+  StepArgs<R> a{};
+  a.x = (R *)l.x;
+  a.energy = (R *)l.energy;
+  a.width = (R *)l.width;
+  a.accept_slots = l.accept_slots;
+  a.status = l.status;
+  a.n = l.n;
+  a.chain_offset = l.chain_offset;
+  a.step_index = l.step_index;
+  a.seed_lo = (uint32_t)l.seed;
+  a.seed_hi = (uint32_t)(l.seed >> 32);
+  a.n_sweeps = l.n_sweeps;
+  a.reject_kind = l.reject_kind;
+  a.split_widths = l.split_widths;
+  a.reject_bound = (R)l.reject_bound;
+  a.temp = (R)l.temp;
+  a.inv_temp = l.temp > 0 ? (R)(1.0 / l.temp) : (R)0;
+  a.inv_temp_log2e = l.temp > 0 ? (R)(1.4426950408889634 / l.temp) : (R)0;
+  a.ratio = (R)l.ratio;
+  a.p = (R)l.target_acceptance;
+  a.damping = (R)l.damping;
+  a.up = (R)(l.ratio * (1.0 - l.target_acceptance) / l.damping);
+  a.down = (R)(-l.ratio * l.target_acceptance / l.damping);
+  // the acceptance slots are sized for 64-thread blocks over all chains; a 256-thread grid uses a quarter of them
+  hipLaunchKernelGGL(k_step_runtime<R>, dim3(grid_of(l.n, l.grid_blocks)), dim3(kBlockThreads), 0, stream, a, p);
+  return hipGetLastError();
+}
+
+template <typename R>
+hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
+  MeasureArgs<R> a{};
+  a.x = (const R *)l.x;
+  a.mean = (R *)l.mean;
+  a.obs_mean = (R *)l.obs_mean;
+  a.n = l.n;
+  const double i = (double)l.measure_count;
+  a.keep = (R)((i - 1.0) / i);
+  a.inv_i = (R)(1.0 / i);
+  hipLaunchKernelGGL(k_measure_runtime<R>, dim3(grid_of(l.n, l.grid_blocks)), dim3(kBlockThreads), 0, stream, a, l.n_real,
+                     l.n_complex);
+  return hipGetLastError();
+}
+
+template <typename R>
+hipError_t init_energy(const EnergyLaunch &l, hipStream_t stream) {
+  RuntimeStep<R> p;
+  if (!fill(p, l.n_real, l.n_complex, GROUP_ALL, l.energy_kind, l.coef_host, l.n_coef, l.coef_device)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_init_energy_runtime<R>, dim3(grid_of(l.n, l.grid_blocks)), dim3(kBlockThreads), 0, stream,
+                     (const R *)l.x, (R *)l.energy, l.n, l.status, p);
+  return hipGetLastError();
+}
+
+// n_real = n_complex = -1: the wildcard set find_kernel_set falls back to above kMaxRegisterDof (me_api.hip)
+const KernelSet kRuntimeF32 = {nullptr, ME_F32, -1, -1, false, false, has_energy, energy_terms, step<float>, nullptr,
+                               measure<float>, init_energy<float>, 0, nullptr, nullptr, false};
+const KernelSet kRuntimeF64 = {nullptr, ME_F64, -1, -1, false, false, has_energy, energy_terms, step<double>, nullptr,
+                               measure<double>, init_energy<double>, 0, nullptr, nullptr, false};
+
+struct Registrar {
+  Registrar() {
+    register_kernel_set(&kRuntimeF32);
+    register_kernel_set(&kRuntimeF64);
+  }
+} registrar;
+
+}  // namespace
+}  // namespace me

@@ -156,3 +156,26 @@ def test_per_device_cache_is_keyed_by_device(tmp_path):
     out = str(tmp_path / "libper_device.so")
     subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", src, "-o", out, "-pthread"], check=True)
     assert ctypes.CDLL(out).me_test_per_device() == 0
+
+
+def test_runtime_dimension_kernel_set_is_the_fallback_beyond_96_dof():
+    """Parameter spaces beyond the register-resident kernels (n_real + 2 n_complex > 96) resolve to the runtime-dimension
+    set of the main library (csrc/me_runtime_dims.hip): separable energies, identity proposal shape."""
+    lib = _capi.load()
+    assert lib.me_supported(_capi.ME_F32, 200, 0, _capi.ENERGY_ISO_QUAD) == 1
+    assert lib.me_supported(_capi.ME_F64, 60, 25, _capi.ENERGY_DIAG_QUAD) == 1
+    assert lib.me_supported(_capi.ME_F32, 200, 0, _capi.ENERGY_DENSE_QUAD) == 0
+    assert lib.me_supported(_capi.ME_F32, 5, 0, _capi.ENERGY_ISO_QUAD) == 0          # small sizes are built on demand instead
+    cfg = _capi.MeConfig()
+    init, coef = np.zeros(200), np.ones(1)
+    cfg.abi_version, cfg.n_chains, cfg.n_real, cfg.n_complex = _capi.ABI_VERSION, 8, 200, 0
+    cfg.target_acceptance, cfg.sampling_width, cfg.temp = 0.3, 0.05, 1.0
+    cfg.energy_kind, cfg.n_energy_coeffs = _capi.ENERGY_ISO_QUAD, 1
+    cfg.energy_coeffs = coef.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    cfg.initial_params = init.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    handle = ctypes.c_void_p()
+    cfg.cov_mode = _capi.COV_REFERENCE
+    assert lib.me_create(ctypes.byref(cfg), ctypes.byref(handle)) == _capi.ME_ERR_UNSUPPORTED
+    assert "identity proposal shape" in _capi.last_error()
+    cfg.cov_mode = _capi.COV_FIXED
+    assert lib.me_create(ctypes.byref(cfg), ctypes.byref(handle)) == _capi.ME_ERR_HIP     # accepted; no GPU here

@@ -1,0 +1,109 @@
+"""GPU tests of the runtime-dimension kernel set (csrc/me_runtime_dims.hip): parameter spaces beyond the 96 real degrees
+of freedom of the register-resident kernels.  The reference has no limit on the number of parameters
+(metropolis_engine.py:41-60).  float64 follows the many-chain oracle on the same Philox streams (1e-9): step_all, fused
+sweeps, group-wise steps of a mixed engine, the hard wall, T = 0, measure(); float32 is checked on stationary moments."""
+import numpy as np
+import pytest
+
+import metropolisengine_amd as me
+from oracle import energies
+from oracle.manychain import ManyChainOracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def _compare(eng, ora, nr, nc):
+    assert np.allclose(eng._get(0), ora.x, rtol=0, atol=TOL)
+    assert np.allclose(eng.energy_total, ora.energy, rtol=0, atol=1e-8)
+    if nr:
+        assert np.allclose(eng.real_group_sampling_width, ora.width_real, rtol=1e-12)
+    if nc:
+        assert np.allclose(eng.complex_group_sampling_width, ora.width_complex, rtol=1e-12)
+    assert np.allclose(eng._get(3), ora.mean, rtol=0, atol=TOL)
+    assert np.allclose(eng.observables_mean, ora.observables_mean, rtol=0, atol=TOL)
+    assert eng.accept_stats() == (ora.accepted, ora.proposed)
+
+
+@pytest.mark.parametrize("temp", [1.0, 0.0], ids=["T1", "T0"])
+def test_130_real_isotropic_follows_the_oracle(temp):
+    nr, n, seed = 130, 197, 31                      # 197 chains: ragged last wavefront
+    x0 = list(np.linspace(-0.2, 0.2, nr))
+    eng = me.MetropolisEngine(me.IsoQuadratic(0.7), None, x0, None, temp=temp, n_chains=n, seed=seed, dtype="f64",
+                              cov_mode="fixed", sampling_width=0.03)
+    ora = ManyChainOracle(nr, 0, energies.iso_quadratic(nr, 0, 0.7), n, seed=seed, temp=temp, initial_real_params=x0,
+                          sampling_width=0.03, adapt_shape=False)
+    for k in range(20):
+        sweeps = 1 if k % 2 else 3                  # one-sweep launches and fused sweeps
+        eng.step_all(sweeps)
+        ora.step(sweeps)
+        eng.measure()
+        ora.measure()
+    _compare(eng, ora, nr, 0)
+    assert 0.05 < ora.accepted / ora.proposed < 0.95 or temp == 0.0
+
+
+def test_mixed_60_real_25_complex_groups_and_wall():
+    nr, nc, n, seed = 60, 25, 130, 32               # D = 110; an odd number of real parameters would shift the pairs
+    rng = np.random.default_rng(3)
+    a, b = rng.uniform(0.5, 3.0, nr), rng.uniform(0.5, 3.0, nc)
+    x0 = [0.9] + [0.0] * (nr - 1)
+    z0 = list(0.05 * (rng.standard_normal(nc) + 1j * rng.standard_normal(nc)))
+    eng = me.MetropolisEngine(me.DiagQuadratic(tuple(a), tuple(b)), me.AbsReal0AtLeast(1.0), x0, z0, temp=0.5, n_chains=n,
+                              seed=seed, dtype="f64", cov_mode="fixed", sampling_width=0.04)
+    ora = ManyChainOracle(nr, nc, energies.diag_quadratic(nr, nc, a, b), n, seed=seed, temp=0.5, initial_real_params=x0,
+                          initial_complex_params=z0, sampling_width=0.04, adapt_shape=False,
+                          reject=lambda p: np.abs(p[:, 0]) >= 1.0)
+    for k in range(12):
+        for op in ("all", "real", "complex", "all"):
+            if op == "all":
+                eng.step_all(2)
+                ora.step(2, group="all")
+            elif op == "real":
+                eng.step_real_group()
+                ora.step(1, group="real")
+            else:
+                eng.step_complex_group()
+                ora.step(1, group="complex")
+        eng.measure()
+        ora.measure()
+    _compare(eng, ora, nr, nc)
+    assert np.allclose(eng.sampling_width, ora.width_all, rtol=1e-12)
+    assert np.all(np.abs(eng._get(0)[:, 0]) < 1.0)
+
+
+def test_odd_dimension_101_real():
+    """D odd: the last Box-Muller pair is half used and the accept uniform is word D + 1."""
+    nr, n, seed = 101, 70, 33
+    x0 = [0.1] * nr
+    eng = me.MetropolisEngine(me.IsoQuadratic(1.0), None, x0, None, temp=1.0, n_chains=n, seed=seed, dtype="f64",
+                              cov_mode="fixed")
+    ora = ManyChainOracle(nr, 0, energies.iso_quadratic(nr, 0, 1.0), n, seed=seed, temp=1.0, initial_real_params=x0, adapt_shape=False)
+    eng.step_all(30)
+    ora.step(30)
+    assert np.allclose(eng._get(0), ora.x, rtol=0, atol=TOL)
+    assert eng.accept_stats() == (ora.accepted, ora.proposed)
+
+
+def test_f32_200_real_stationary_variances():
+    nr, n = 200, 4096
+    a = np.random.default_rng(4).uniform(0.5, 4.0, nr)
+    eng = me.MetropolisEngine(me.DiagQuadratic(tuple(a)), None, [0.0] * nr, None, temp=1.0, n_chains=n, seed=34,
+                              cov_mode="fixed", sampling_width=0.05)
+    eng.step_all(4000)
+    x = eng._get(0)
+    var = x.var(axis=0)
+    assert np.all(np.abs(var * 2 * a - 1) < 8 * np.sqrt(2.0 / n))          # Var x_i = T / (2 a_i)
+    assert 0.15 < eng.acceptance_rate() < 0.5
+    assert np.allclose(eng.energy_total, (a * x * x).sum(axis=1), rtol=2e-4)   # the ledger is the energy of the state
+
+
+def test_unsupported_combinations_fail_loudly():
+    with pytest.raises(NotImplementedError, match="identity proposal shape"):
+        me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 120, None, temp=1.0, n_chains=8)      # cov_mode="reference"
+    with pytest.raises(NotImplementedError):
+        me.MetropolisEngine(me.DenseQuadratic(np.identity(120)), None, [0.0] * 120, None, temp=1.0, n_chains=8,
+                            cov_mode="fixed")
+    eng = me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 120, None, temp=1.0, n_chains=8, cov_mode="fixed")
+    with pytest.raises(NotImplementedError):
+        eng.covariance_matrix_real

@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p tools/variants/obj_$name
-for u in me_api me_generic me_statistics; do
+for u in me_api me_generic me_statistics me_runtime_dims; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include "$@" -c metropolisengine_amd/csrc/$u.hip -o tools/variants/obj_$name/$u.o &
 done
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include -DME_NR=${NR:-16} -DME_NC=${NC:-0} -DME_DENSE=${DENSE:-0} -DME_PER_CHAIN=${PER_CHAIN:-1} "$@" \

@@ -2,7 +2,8 @@
 kernel into profiles/rNN_pmc_traffic.json, which bench.py reports as roofline.traffic.
 
     python tools/pmc_summary.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> [kernel substring]
-                                [chains_log2] [algorithmic bytes per chain-step] ["bench.py flags of the passes"] > out.json
+                                [chains_log2] [algorithmic bytes per chain-step] ["bench.py flags of the passes"]
+                                [last N dispatches only] > out.json
 
 Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters
 are in KiB; FETCH_SIZE under-reports by 2x on this part for the dword-per-lane buffer loads the kernel issues, which
@@ -23,11 +24,13 @@ def per_dispatch(directory, counter, needle):
             for row in csv.DictReader(fh):
                 if row.get("Counter_Name") != counter or needle not in row.get("Kernel_Name", ""):
                     continue
-                key = (path, row.get("Dispatch_Id"))
+                key = (path, int(row.get("Dispatch_Id")))
                 sums[key] = sums.get(key, 0.0) + float(row["Counter_Value"])
-    return list(sums.values())
+    ordered = [sums[k] for k in sorted(sums)]
+    return ordered[-LAST_N:] if LAST_N else ordered
 
 
+LAST_N = int(sys.argv[7]) if len(sys.argv) > 7 else 0      # e.g. only the measures after the 50-measure threshold
 fetch_dir, write_dir = sys.argv[1], sys.argv[2]
 needle = sys.argv[3] if len(sys.argv) > 3 else "k_step<float, 16, 0"
 fetch = per_dispatch(fetch_dir, "FETCH_SIZE", needle)
@@ -40,8 +43,8 @@ per_chain = int(sys.argv[5]) if len(sys.argv) > 5 else 144
 flags = sys.argv[6] if len(sys.argv) > 6 else "--gpus 1 --steps 50 --warmup 20 --cpu-seconds 0 --fused-sweeps 0 --extras 0"
 chains = 1 << chains_log2
 out = {
-    "command": "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 bench.py %s "
-               "(one pass per counter); tools/pmc_summary.py" % flags,
+    "command": "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 %s "
+               "(one pass per counter); tools/pmc_summary.py" % (flags if flags.startswith("tools/") else "bench.py " + flags),
     "kernel": needle + " ... at 2^%d chains, 1 sweep per launch" % chains_log2,
     "launches_sampled": min(len(fetch), len(write)),
     "FETCH_SIZE_raw_KiB_median": f_kib,
