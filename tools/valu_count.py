@@ -28,14 +28,17 @@ with tempfile.TemporaryDirectory() as tmp:
     text = open(out).read()
 start = text.index(KERNEL + ":")
 body = text[start:text.index("s_endpgm", start)].splitlines()
-# the sweep loop: the inner loop with the largest body (the kernel's tail has a small one summing nothing of interest)
+# the sweep loop: the innermost-level loop with the largest body (other loops of the kernel: the grid-stride loop around
+# it, the float64 build's table copy at the top, the slot sum at the tail)
 best = None
 for i, line in enumerate(body):
     if "Inner Loop Header" not in line:
         continue
-    j = i if body[i].startswith(".LBB") else i - 1
+    j = i
+    while j >= 0 and not body[j].startswith(".LBB"):
+        j -= 1
     label = re.match(r"(\.LBB\d+_\d+):", body[j]).group(1)
-    ends = [k for k, l in enumerate(body) if k > j and re.search(r"s_cbranch\w*\s+" + re.escape(label) + r"\b", l)]
+    ends = [k for k, l in enumerate(body) if k > j and re.search(r"s_c?branch\w*\s+" + re.escape(label) + r"\b", l)]
     if ends and (best is None or ends[-1] - j > best[1] - best[0]):
         best = (j, ends[-1])
 if best is None:
