@@ -184,13 +184,53 @@ void to_device_type(const double *src, size_t count, int dtype, std::vector<unsi
 }
 
 // broadcast one host row (doubles) to every chain of a component-major device field
-int broadcast(me_engine *e, void *dst, const std::vector<double> &row) {
+// `tiled`: dst is one of the packed covariance / factor fields (tile-major, me_device.h: TiledField)
+int broadcast(me_engine *e, void *dst, const std::vector<double> &row, bool tiled = false) {
   std::vector<unsigned char> bytes;
   to_device_type(row.data(), row.size(), e->dtype, bytes);
   ME_HIP(e, hipMemcpyAsync(e->row_dev, bytes.data(), bytes.size(), hipMemcpyHostToDevice, e->stream));
-  ME_HIP(e, launch_broadcast_rows(dst, e->row_dev, (int)row.size(), e->n, e->dtype, e->stream));
+  if (tiled) ME_HIP(e, launch_broadcast_tiled(dst, e->row_dev, (int)row.size(), e->n, e->dtype, e->stream));
+  else ME_HIP(e, launch_broadcast_rows(dst, e->row_dev, (int)row.size(), e->n, e->dtype, e->stream));
   ME_HIP(e, hipStreamSynchronize(e->stream));   // row_dev / bytes are reused by the next call
   return ME_OK;
+}
+
+int check_status(me_engine *e);
+// Host <-> device copy of chains [chain_begin, chain_begin + n_chains) of a TILE-major packed field (covariance, factor:
+// entry k of chain c at ((c >> 6) * entries + k) * 64 + (c & 63), me_device.h).  The chain range covers a contiguous run of
+// whole tiles on the device: one copy each way, the gather / scatter into the caller's [chain][entry] doubles on the host.
+// Exactly one of dst / src is non-null; a partial first / last tile is read back before it is rewritten.
+int copy_tiled(me_engine *e, void *field_ptr, int entries, int64_t chain_begin, int64_t n_chains, double *dst, const double *src) {
+  const int64_t tile0 = chain_begin >> 6, tile1 = (chain_begin + n_chains - 1) >> 6;
+  const size_t tile_values = (size_t)entries * 64, n_values = (size_t)(tile1 - tile0 + 1) * tile_values;
+  unsigned char *dev = (unsigned char *)field_ptr + (size_t)tile0 * tile_values * e->esize;
+  std::vector<unsigned char> tmp(n_values * e->esize);
+  const bool whole = (chain_begin & 63) == 0 && (((chain_begin + n_chains) & 63) == 0 || chain_begin + n_chains == e->n);
+  if (dst || !whole) {
+    ME_HIP(e, hipMemcpyAsync(tmp.data(), dev, tmp.size(), hipMemcpyDeviceToHost, e->stream));
+    ME_HIP(e, hipStreamSynchronize(e->stream));
+  }
+  auto at = [&](int64_t c, int k) { return (size_t)((c >> 6) - tile0) * tile_values + (size_t)k * 64 + (size_t)(c & 63); };
+  if (e->dtype == ME_F32) {
+    float *t = reinterpret_cast<float *>(tmp.data());
+    for (int64_t i = 0; i < n_chains; ++i)
+      for (int k = 0; k < entries; ++k) {
+        if (dst) dst[i * entries + k] = (double)t[at(chain_begin + i, k)];
+        else t[at(chain_begin + i, k)] = (float)src[i * entries + k];
+      }
+  } else {
+    double *t = reinterpret_cast<double *>(tmp.data());
+    for (int64_t i = 0; i < n_chains; ++i)
+      for (int k = 0; k < entries; ++k) {
+        if (dst) dst[i * entries + k] = t[at(chain_begin + i, k)];
+        else t[at(chain_begin + i, k)] = src[i * entries + k];
+      }
+  }
+  if (src) {
+    ME_HIP(e, hipMemcpyAsync(dev, tmp.data(), tmp.size(), hipMemcpyHostToDevice, e->stream));
+    ME_HIP(e, hipStreamSynchronize(e->stream));
+  }
+  return dst ? check_status(e) : ME_OK;
 }
 
 int field_info(me_engine *e, int field, void **ptr, int *comps) {
@@ -401,7 +441,7 @@ int me_create(const me_config *c, me_engine **out) {
   {
     const long long esz = c->dtype == ME_F32 ? 4 : 8;
     const long long limit = 1ll << 32;
-    if (keep_per_chain && (long long)packed_total(c->n_real, c->n_complex) * c->n_chains * esz >= limit) {
+    if (keep_per_chain && (long long)packed_total(c->n_real, c->n_complex) * ((c->n_chains + 63) / 64 * 64) * esz >= limit) {
       if (c->cov_mode == ME_COV_REFERENCE)
         return fail(nullptr, ME_ERR_UNSUPPORTED,
                     "the per-chain covariance field would exceed 4 GiB on this engine; shard the chains over more "
@@ -468,8 +508,8 @@ int me_create(const me_config *c, me_engine **out) {
   ME_CREATE_HIP(hipMalloc(&e->mean, n * e->d * es));
   ME_CREATE_HIP(hipMalloc(&e->obs_mean, n * e->nobs * es));
   if (keep_per_chain || (!ks->per_chain_cov && ks->tracks_cov && (c->flags & ME_FLAG_TRACK_COVARIANCE)))
-    ME_CREATE_HIP(hipMalloc(&e->cov, n * e->p * es));
-  if (keep_per_chain) ME_CREATE_HIP(hipMalloc(&e->factor, n * e->p * es));
+    ME_CREATE_HIP(hipMalloc(&e->cov, (n + 63) / 64 * 64 * e->p * es));      // tile-major: whole 64-chain tiles
+  if (keep_per_chain) ME_CREATE_HIP(hipMalloc(&e->factor, (n + 63) / 64 * 64 * e->p * es));
   ME_CREATE_HIP(hipMalloc(&e->shared_factor, (size_t)e->p * es));
   if (e->nc == 0) ME_CREATE_HIP(hipMalloc(&e->shared_full, (size_t)e->nr * e->nr * es));
   if (e->shared_full && ks->prepare_matrix) ME_CREATE_HIP(hipMalloc(&e->shared_image, ks->matrix_image_bytes));
@@ -554,8 +594,8 @@ int me_create(const me_config *c, me_engine **out) {
   int rc = ME_OK;
   std::vector<double> width_row((size_t)e->width_rows, c->sampling_width);
   if ((rc = broadcast(e, e->x, init)) || (rc = broadcast(e, e->mean, init)) || (rc = broadcast(e, e->obs_mean, obs)) ||
-      (rc = broadcast(e, e->width, width_row)) || (e->cov && (rc = broadcast(e, e->cov, c0))) ||
-      (e->factor && (rc = broadcast(e, e->factor, f0)))) {
+      (rc = broadcast(e, e->width, width_row)) || (e->cov && (rc = broadcast(e, e->cov, c0, true))) ||
+      (e->factor && (rc = broadcast(e, e->factor, f0, true)))) {
     g_create_error = e->err;
     release(e);
     return rc;
@@ -845,6 +885,7 @@ int me_get(me_engine *e, int32_t field, int64_t chain_begin, int64_t n_chains, d
   int rc = field_info(e, field, &ptr, &comps);
   if (rc != ME_OK) return rc;
   if (n_chains == 0) return ME_OK;
+  if (field == ME_FIELD_COV || field == ME_FIELD_FACTOR) return copy_tiled(e, ptr, comps, chain_begin, n_chains, dst, nullptr);
   std::vector<unsigned char> tmp((size_t)comps * n_chains * e->esize);
   for (int r = 0; r < comps; ++r)
     ME_HIP(e, hipMemcpyAsync(tmp.data() + (size_t)r * n_chains * e->esize,
@@ -877,6 +918,12 @@ int me_set(me_engine *e, int32_t field, int64_t chain_begin, int64_t n_chains, c
   if (field == ME_FIELD_WIDTH && e->width_rows == 3 && (chain_begin != 0 || n_chains != e->n))
     return fail(e, ME_ERR_INVALID, "widths of a mixed engine must be set for all chains at once");
   if (n_chains == 0) return ME_OK;
+  if (field == ME_FIELD_COV || field == ME_FIELD_FACTOR) {
+    rc = copy_tiled(e, ptr, comps, chain_begin, n_chains, nullptr, src);
+    if (rc != ME_OK) return rc;
+    if (field == ME_FIELD_FACTOR) e->cov_kind = CK_PER_CHAIN;
+    return ME_OK;
+  }
   std::vector<unsigned char> tmp((size_t)comps * n_chains * e->esize);
   if (e->dtype == ME_F32) {
     float *t = reinterpret_cast<float *>(tmp.data());

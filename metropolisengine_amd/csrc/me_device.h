@@ -175,15 +175,58 @@ struct Field {
   }
 };
 
+// The packed per-chain covariance / factor fields are TILE-major: [tile of 64 chains][P entries][64 lanes], i.e. entry k of
+// chain c sits at ((c >> 6) * P + k) * 64 + (c & 63).  A wavefront's whole matrix is then ONE contiguous run of P x 256
+// bytes (34 KiB at 16 real parameters in float32) instead of P rows that lie a whole field row (4 MiB at 2^20 chains)
+// apart: memory-only probes of the access patterns (tools/dev/rows_probe*.hip): k_step with per-chain factors 118 -> 105 us,
+// k_measure (16,0) 412 -> 388 us, and the spread between runs that comes from where 336 separate row streams land in
+// physical memory goes away.  (For the STATE the component-major layout costs nothing: 18-66 rows)
+// Same interface as Field; `tile_off` = tiled_offset<R>(c, P), entry offsets are compile-time constants after unrolling.
+template <typename R>
+__device__ __forceinline__ unsigned int tiled_offset(long long c, int entries) {
+  return (unsigned int)(((c >> 6) * (long long)entries * 64 + (c & 63)) * (long long)sizeof(R));
+}
+template <typename R>
+struct TiledField {
+  __amdgpu_buffer_rsrc_t rsrc;
+  __device__ __forceinline__ TiledField(const R *base, long long n, int entries)
+      : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<R *>(base), 0,
+                                               (unsigned int)(((n + 63) >> 6) * (long long)entries * 64 * (long long)sizeof(R)),
+                                               0x00020000)) {}
+  static constexpr unsigned int kEntryBytes = 64u * (unsigned int)sizeof(R);
+  template <int AUX>
+  __device__ __forceinline__ R load_aux(int k, unsigned int tile_off) const {
+    if constexpr (sizeof(R) == 4) {
+      return __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b32(rsrc, tile_off, (unsigned int)k * kEntryBytes, AUX));
+    } else {
+      const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, tile_off, (unsigned int)k * kEntryBytes, AUX);
+      return __builtin_bit_cast(R, v);
+    }
+  }
+  template <int AUX>
+  __device__ __forceinline__ void store_aux(int k, unsigned int tile_off, R value) const {
+    if constexpr (sizeof(R) == 4) {
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, value), rsrc, tile_off, (unsigned int)k * kEntryBytes, AUX);
+    } else {
+      using v2 = decltype(__builtin_amdgcn_raw_buffer_load_b64(rsrc, 0u, 0u, 0));
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2, value), rsrc, tile_off, (unsigned int)k * kEntryBytes, AUX);
+    }
+  }
+  __device__ __forceinline__ R load(int k, unsigned int tile_off) const { return load_aux<0>(k, tile_off); }
+  __device__ __forceinline__ R load_nt(int k, unsigned int tile_off) const { return load_aux<ME_NT_AUX>(k, tile_off); }
+  __device__ __forceinline__ void store(int k, unsigned int tile_off, R value) const { store_aux<0>(k, tile_off, value); }
+  __device__ __forceinline__ void store_nt(int k, unsigned int tile_off, R value) const { store_aux<ME_NT_AUX>(k, tile_off, value); }
+};
+
 // accesses of k_measure / k_factor to the packed covariance and factor fields; NT: streamed once per launch from / to
 // HBM (the launcher decides by working-set size, me_kernels.hip)
-template <bool NT, typename R>
-__device__ __forceinline__ R packed_load(const Field<R> &f, int row, unsigned int chain_off) {
+template <bool NT, class F>
+__device__ __forceinline__ auto packed_load(const F &f, int row, unsigned int chain_off) {
   if constexpr (NT) return f.load_nt(row, chain_off);
   else return f.load(row, chain_off);
 }
-template <bool NT, typename R>
-__device__ __forceinline__ void packed_store(const Field<R> &f, int row, unsigned int chain_off, R value) {
+template <bool NT, class F, typename R>
+__device__ __forceinline__ void packed_store(const F &f, int row, unsigned int chain_off, R value) {
   if constexpr (NT) f.store_nt(row, chain_off, value);
   else f.store(row, chain_off, value);
 }
@@ -444,7 +487,8 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   // reference's function touches; by default there is one coherent ledger.
   const bool stale_total = MIXED && GROUP == GROUP_ALL && a.stale_total != 0;
   constexpr bool PER_CHAIN = CK == CK_PER_CHAIN || CK == CK_PER_CHAIN_NT;
-  const Field<R> ffac(a.factor, a.n, PER_CHAIN ? NR * (NR + 1) / 2 + NC * NC : 0);
+  constexpr int PF = PER_CHAIN ? NR * (NR + 1) / 2 + NC * NC : 0;
+  const TiledField<R> ffac(a.factor, a.n, PF);
   for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
     R x[D];
@@ -464,15 +508,16 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
       }
     }
     const unsigned long long gid = a.chain_offset + (unsigned long long)c;
-    // CK_PER_CHAIN(_NT) reads element k at factor[k*n + c] (coalesced; hipcc hoists all of them out of the sweep loop, so
+    [[maybe_unused]] const unsigned int toff = tiled_offset<R>(c, PF);
+    // CK_PER_CHAIN(_NT) reads entry k of the chain's tile (coalesced, tile-major; hipcc hoists all of them out of the sweep loop, so
     // the factor is read once per launch); CK_SHARED reads factor[k] (wave-uniform scalar loads).  The _NT variant reads
     // non-temporally: chosen by the launcher when the working set cannot stay in the Infinity Cache (me_kernels.hip).
     // Tried and dropped: handing the entries out of two alternating register batches (106 instead of 221 VGPRs, four
     // wavefronts per SIMD instead of two) changed nothing -- this kernel sits on the memory-only floor of its access
     // pattern at either occupancy (tools/dev/rows_probe3.hip).
     auto fac = [&](int k) -> R {
-      if constexpr (CK == CK_PER_CHAIN_NT) return ffac.load_nt(k, coff);
-      else if constexpr (CK == CK_PER_CHAIN) return ffac.load(k, coff);
+      if constexpr (CK == CK_PER_CHAIN_NT) return ffac.load_nt(k, toff);
+      else if constexpr (CK == CK_PER_CHAIN) return ffac.load(k, toff);
       else return a.factor[k];
     };
 
@@ -729,11 +774,12 @@ __global__ void __launch_bounds__(kStepThreads, ME_MEASURE_WAVES) k_measure(Meas
   // Large matrices (P > kMaxPackedInRegisters) are statistics only (no factors, FUSED = false) and take the streaming
   // path below; their field may pass the 4 GiB one descriptor spans and is walked with a 64-bit pointer instead.
   constexpr bool STREAM = PER_CHAIN_COV && P > kMaxPackedInRegisters;
-  const Field<R> fcov(a.cov, a.n, (PER_CHAIN_COV && !STREAM) ? P : 0);
-  const Field<R> ffac(a.factor, a.n, (PER_CHAIN_COV && FUSED) ? P : 0);
+  const TiledField<R> fcov(a.cov, a.n, (PER_CHAIN_COV && !STREAM) ? P : 0);
+  const TiledField<R> ffac(a.factor, a.n, (PER_CHAIN_COV && FUSED) ? P : 0);
   __shared__ R s_delta[STREAM ? D : 1][kStepThreads];
   for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
+    [[maybe_unused]] const unsigned int toff = tiled_offset<R>(c, P);      // the chain's place in the packed fields
     // Every phase issues ALL its loads before its first store: the compiler cannot prove that a store to one field does
     // not alias the next load of another, so interleaved load-update-store sequences were emitted strictly in order
     // with two loads in flight per wavefront (k_measure<64,0> ran at 0.36 of the HBM peak that way).
@@ -783,7 +829,9 @@ __global__ void __launch_bounds__(kStepThreads, ME_MEASURE_WAVES) k_measure(Meas
           // delta is parked in LDS (lane-linear, conflict-free) so that the walk over the packed entries can be a
           // ROLLED loop: unrolled, 2 080 entries are ~100 KB of code and the kernel becomes instruction-fetch bound.
           // One 64-bit pointer per lane steps by whole rows (the packed order is exactly the loop order).
-          R *p = a.cov + c;
+          // tile-major: the chain's entries lie 64 values apart from the start of its tile
+          R *p = a.cov + (c >> 6) * (long long)P * 64 + (c & 63);
+          constexpr long long ts = 64;
           for (int i = 0; i < NR; ++i) {
             const R di = s_delta[i][threadIdx.x];
             int j = 0;
@@ -792,25 +840,25 @@ __global__ void __launch_bounds__(kStepThreads, ME_MEASURE_WAVES) k_measure(Meas
             for (; j + 16 <= i; j += 16) {
               R v[16];
 #pragma unroll
-              for (int u = 0; u < 16; ++u) v[u] = p[u * a.n];
+              for (int u = 0; u < 16; ++u) v[u] = p[u * ts];
 #pragma unroll
-              for (int u = 0; u < 16; ++u) p[u * a.n] = v[u] * a.cov_keep + di * s_delta[j + u][threadIdx.x] * a.inv_i;
-              p += 16 * a.n;
+              for (int u = 0; u < 16; ++u) p[u * ts] = v[u] * a.cov_keep + di * s_delta[j + u][threadIdx.x] * a.inv_i;
+              p += 16 * ts;
             }
             for (; j + 4 <= i; j += 4) {
               R v[4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) v[u] = p[u * a.n];
+              for (int u = 0; u < 4; ++u) v[u] = p[u * ts];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) p[u * a.n] = v[u] * a.cov_keep + di * s_delta[j + u][threadIdx.x] * a.inv_i;
-              p += 4 * a.n;
+              for (int u = 0; u < 4; ++u) p[u * ts] = v[u] * a.cov_keep + di * s_delta[j + u][threadIdx.x] * a.inv_i;
+              p += 4 * ts;
             }
             for (; j < i; ++j) {
               *p = *p * a.cov_keep + di * s_delta[j][threadIdx.x] * a.inv_i;
-              p += a.n;
+              p += ts;
             }
             *p = *p * a.cov_keep + di * di * a.inv_i + eps;
-            p += a.n;
+            p += ts;
           }
           for (int i = 0; i < NC; ++i) {
             const R ai = s_delta[NR + i][threadIdx.x], bi = s_delta[NR + NC + i][threadIdx.x];
@@ -818,30 +866,30 @@ __global__ void __launch_bounds__(kStepThreads, ME_MEASURE_WAVES) k_measure(Meas
             for (; j + 8 <= i; j += 8) {          // eight (Re, Im) pairs: sixteen loads, then the updates
               R v[16];
 #pragma unroll
-              for (int u = 0; u < 16; ++u) v[u] = p[u * a.n];
+              for (int u = 0; u < 16; ++u) v[u] = p[u * ts];
 #pragma unroll
               for (int u = 0; u < 8; ++u) {
                 const R aj = s_delta[NR + j + u][threadIdx.x], bj = s_delta[NR + NC + j + u][threadIdx.x];
-                p[(2 * u) * a.n] = v[2 * u] * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
-                p[(2 * u + 1) * a.n] = v[2 * u + 1] * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
+                p[(2 * u) * ts] = v[2 * u] * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
+                p[(2 * u + 1) * ts] = v[2 * u + 1] * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
               }
-              p += 16 * a.n;
+              p += 16 * ts;
             }
             for (; j < i; ++j) {
               const R aj = s_delta[NR + j][threadIdx.x], bj = s_delta[NR + NC + j][threadIdx.x];
-              const R re = p[0], im = p[a.n];
+              const R re = p[0], im = p[ts];
               p[0] = re * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
-              p[a.n] = im * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
-              p += 2 * a.n;
+              p[ts] = im * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
+              p += 2 * ts;
             }
             *p = *p * a.cov_keep + (ai * ai + bi * bi) * a.inv_i + eps_c;
-            p += a.n;
+            p += ts;
           }
         } else {
         // the packed matrix is read whole, then updated and written back (FUSED keeps it for the Cholesky anyway)
         R m[P];
 #pragma unroll
-        for (int k = 0; k < P; ++k) m[k] = packed_load<NT>(fcov, k, coff);
+        for (int k = 0; k < P; ++k) m[k] = packed_load<NT>(fcov, k, toff);
 #pragma unroll
         for (int i = 0; i < NR; ++i)
 #pragma unroll
@@ -849,7 +897,7 @@ __global__ void __launch_bounds__(kStepThreads, ME_MEASURE_WAVES) k_measure(Meas
             const int k = tri(i, j);
             R v = m[k] * a.cov_keep + delta[i] * delta[j] * a.inv_i;
             if (i == j) v += eps;
-            packed_store<NT>(fcov, k, coff, v);
+            packed_store<NT>(fcov, k, toff, v);
             m[k] = v;
           }
 #pragma unroll
@@ -861,21 +909,21 @@ __global__ void __launch_bounds__(kStepThreads, ME_MEASURE_WAVES) k_measure(Meas
             const int kr = cre(PR, i, j), ki = cim(PR, i, j);
             const R vr = m[kr] * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
             const R vi = m[ki] * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
-            packed_store<NT>(fcov, kr, coff, vr);
-            packed_store<NT>(fcov, ki, coff, vi);
+            packed_store<NT>(fcov, kr, toff, vr);
+            packed_store<NT>(fcov, ki, toff, vi);
             m[kr] = vr;
             m[ki] = -vi;   // the proposals use conj(K) (quirk Q3, :292-298)
           }
           const int kd = cdiag(PR, i);
           const R vd = m[kd] * a.cov_keep + (ai * ai + bi * bi) * a.inv_i + eps_c;
-          packed_store<NT>(fcov, kd, coff, vd);
+          packed_store<NT>(fcov, kd, toff, vd);
           m[kd] = vd;
         }
         if constexpr (FUSED) {
           if (a.write_factor) {
             cholesky_packed<R, NR, NC>(m, bad_pivot);
 #pragma unroll
-            for (int k = 0; k < P; ++k) packed_store<NT>(ffac, k, coff, m[k]);
+            for (int k = 0; k < P; ++k) packed_store<NT>(ffac, k, toff, m[k]);
           }
         }
         }   // !STREAM
@@ -892,19 +940,19 @@ __global__ void __launch_bounds__(kStepThreads) k_factor(const R *cov, R *factor
   constexpr int P = PR + NC * NC;
   bool bad_pivot = false;
   const long long stride = (long long)gridDim.x * kStepThreads;
-  const Field<R> fcov(cov, n, P), ffac(factor, n, P);
+  const TiledField<R> fcov(cov, n, P), ffac(factor, n, P);
   for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < n; c += stride) {
-    const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
+    const unsigned int toff = tiled_offset<R>(c, P);
     R m[P];
 #pragma unroll
-    for (int k = 0; k < P; ++k) m[k] = packed_load<NT>(fcov, k, coff);
+    for (int k = 0; k < P; ++k) m[k] = packed_load<NT>(fcov, k, toff);
 #pragma unroll
     for (int i = 0; i < NC; ++i)
 #pragma unroll
       for (int j = 0; j < i; ++j) m[cim(PR, i, j)] = -m[cim(PR, i, j)];   // conj(K) (quirk Q3, :292-298)
     cholesky_packed<R, NR, NC>(m, bad_pivot);
 #pragma unroll
-    for (int k = 0; k < P; ++k) packed_store<NT>(ffac, k, coff, m[k]);
+    for (int k = 0; k < P; ++k) packed_store<NT>(ffac, k, toff, m[k]);
   }
   if (bad_pivot) atomicOr(status, (unsigned int)ST_BAD_PIVOT);
 }

@@ -11,6 +11,14 @@ __global__ void __launch_bounds__(kBlockThreads) k_broadcast_rows(R *dst, const 
     for (int r = 0; r < rows; ++r) dst[(long long)r * n + c] = row_values[r];
 }
 
+// the same for a tile-major packed field [tile of 64 chains][entries][64 lanes] (me_device.h: TiledField)
+template <typename R>
+__global__ void __launch_bounds__(kBlockThreads) k_broadcast_tiled(R *dst, const R *entry_values, int entries, long long n_padded) {
+  const long long total = n_padded * entries, stride = (long long)gridDim.x * kBlockThreads;
+  for (long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x; i < total; i += stride)
+    dst[i] = entry_values[(i >> 6) % entries];
+}
+
 // (i, j), i >= j, of packed lower-triangle index p
 __device__ __forceinline__ void pair_of(int p, int &i, int &j) {
   i = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
@@ -184,6 +192,21 @@ hipError_t launch_broadcast_rows(void *dst, const void *row_values, int rows, lo
   else
     hipLaunchKernelGGL(k_broadcast_rows<double>, dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream, (double *)dst,
                        (const double *)row_values, rows, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_broadcast_tiled(void *dst, const void *entry_values, int entries, long long n, int dtype,
+                                  hipStream_t stream) {
+  const long long n_padded = (n + 63) / 64 * 64;
+  long long blocks = (n_padded * entries + kBlockThreads - 1) / kBlockThreads;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  if (dtype == ME_F32)
+    hipLaunchKernelGGL(k_broadcast_tiled<float>, dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream, (float *)dst,
+                       (const float *)entry_values, entries, n_padded);
+  else
+    hipLaunchKernelGGL(k_broadcast_tiled<double>, dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream, (double *)dst,
+                       (const double *)entry_values, entries, n_padded);
   return hipGetLastError();
 }
 

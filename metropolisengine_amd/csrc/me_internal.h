@@ -128,6 +128,9 @@ bool has_dims(int dtype, int n_real, int n_complex);
 // dst[r*n + c] = row_values[r] for r < rows, c < n   (broadcast one chain's vector to all chains)
 hipError_t launch_broadcast_rows(void *dst, const void *row_values, int rows, long long n, int dtype,
                                  hipStream_t stream);
+// dst[((c >> 6) * entries + k) * 64 + (c & 63)] = entry_values[k]: the tile-major packed covariance / factor fields
+hipError_t launch_broadcast_tiled(void *dst, const void *entry_values, int entries, long long n, int dtype,
+                                  hipStream_t stream);
 // Ensemble sums (see me_pooled_moments in the public header).  out must hold moments_size doubles; `slots` are the
 // per-wavefront acceptance counters (summed by the finishing kernel), proposed is host-known.
 hipError_t launch_pool_reduce(const void *x, long long n, int n_real, int n_complex, int dtype,

@@ -54,14 +54,15 @@ __global__ void __launch_bounds__(kStepThreads) k_step_magphase(StepArgs<R> a, E
   bool bad_energy = false, bad_width = false;
   const long long stride = (long long)gridDim.x * kStepThreads;
   using Ledger = EnergyLedger<R, Energy, MIXED ? GROUP_COMPLEX : GROUP_ALL>;   // the complex group's terms (:183-189)
-  const Field<R> fx(a.x, a.n, D), fe(a.energy, a.n, Ledger::T), fw(a.width, a.n, MIXED ? 3 : 1), fcov(a.factor, a.n, P);
+  const Field<R> fx(a.x, a.n, D), fe(a.energy, a.n, Ledger::T), fw(a.width, a.n, MIXED ? 3 : 1);
+  const TiledField<R> fcov(a.factor, a.n, P);      // the covariance field (tile-major)
   for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
     R x[D], kdiag[NC];
 #pragma unroll
     for (int d = 0; d < D; ++d) x[d] = fx.load(d, coff);
 #pragma unroll
-    for (int j = 0; j < NC; ++j) kdiag[j] = fcov.load(cdiag(PR, j), coff);
+    for (int j = 0; j < NC; ++j) kdiag[j] = fcov.load(cdiag(PR, j), tiled_offset<R>(c, P));
     Ledger ledger;
     ledger.load(fe, coff);
     R w = fw.load(WROW, coff);
