@@ -22,10 +22,34 @@ def _cycle(eng, cycles, steps):
         eng.measure()
 
 
-def test_config3_full_size_adaptive_covariance():
+def test_config2_full_size_float64_headline():
+    """The headline workload in the reference's arithmetic: 2^20 chains x 16 real parameters, float64.  Any sub-range is
+    bitwise the small engine that owns the same global chain ids (so the 1e-9 oracle parity of the small sizes carries
+    over chain by chain), launch splitting does not change results, and the stationary variance is T / (2 a)."""
+    n, sub, off = 1 << 20, 200, (1 << 20) - 64 * 99 - 13
+    kw = dict(temp=1.0, seed=2026, dtype="f64")
+    full = me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 16, None, n_chains=n, **kw)
+    part = me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 16, None, n_chains=sub, chain_offset=off, **kw)
+    full.step_all(64)                           # fused sweeps ...
+    for _ in range(8):                          # ... against one-sweep and short fused launches of the same 64 steps
+        part.step_all()
+        part.step_all(7)
+    for field in (_capi.FIELD_PARAMS, _capi.FIELD_ENERGY, _capi.FIELD_WIDTH):
+        assert np.array_equal(full._get(field, off, sub), part._get(field)), field
+    full.step_all(2500)
+    st = moments_to_statistics(full.pooled_moments(), 16, 0)
+    assert np.all(np.abs(np.diag(st["covariance"]) * 2.0 - 1.0) < 0.01 + 6 * np.sqrt(2.0 / n))
+    assert np.all(np.abs(st["mean"]) < 6 * np.sqrt(0.5 / n) + 1e-3)
+    assert 0.2 < st["acceptance_rate"] < 0.45
+    x = full._get(_capi.FIELD_PARAMS, 0, 4096)
+    assert np.allclose(full._get(_capi.FIELD_ENERGY, 0, 4096)[:, 0], (x * x).sum(axis=1), rtol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_config3_full_size_adaptive_covariance(dtype):
     n, sub, off = 1 << 20, 192, (1 << 20) - 4096 - 37
     a = b = (1.0, 2.0, 4.0, 8.0)
-    kw = dict(temp=1.0, seed=2026)
+    kw = dict(temp=1.0, seed=2026, dtype=dtype)
     full = me.MetropolisEngine(me.DiagQuadratic(a, b), None, [0.0] * 4, [0j] * 4, n_chains=n, **kw)
     part = me.MetropolisEngine(me.DiagQuadratic(a, b), None, [0.0] * 4, [0j] * 4, n_chains=sub, chain_offset=off, **kw)
     for eng in (full, part):
