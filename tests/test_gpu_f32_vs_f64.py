@@ -96,6 +96,28 @@ def test_config5_user_plugin_and_wall_50_sweeps():
     assert np.all(np.abs(f32._get(0)[:, 0]) < 1.0)
 
 
+@pytest.mark.parametrize("mode", ["fixed", "pooled"], ids=["identity-shape", "shared-factor"])
+def test_config4_dense64_matrix_core_kernels_50_sweeps(mode):
+    """Config 4: the float32 matrix-core kernel (split-bf16, me_dense_bf16x3.h) against the float64 one
+    (v_mfma_f64_16x16x4_f64, me_dense_f64.h, itself pinned to the oracle as a trajectory in test_gpu_dense_f64.py):
+    identical accept sequences over 50 sweeps, identity shape and the shared factor L g on the matrix cores."""
+    m = np.random.default_rng(5).standard_normal((64, 64))
+    amat = m @ m.T / 64 + np.identity(64)
+
+    def make(dtype, n):
+        eng = me.MetropolisEngine(me.DenseQuadratic(amat), None, [0.0] * 64, None, temp=1.0, n_chains=n, seed=2026, dtype=dtype,
+                                  cov_mode=mode, sampling_width=0.2)
+        if mode == "pooled":
+            b = np.random.default_rng(9).standard_normal((64, 64))
+            cov = 0.5 * np.linalg.inv(amat) + 0.02 * (b @ b.T) / 64
+            chol = np.linalg.cholesky(cov)
+            eng.set_shared_factor(chol[np.tril_indices(64)])
+        return eng
+    f32, f64 = _pair(make, 4096, lambda e: e.step_all(200))
+    same = _compare(f32, f64, 50)
+    assert same.mean() > 0.99
+
+
 def test_width_recursion_does_not_drift_over_2000_steps():
     """Ensemble-mean width of float32 against float64 every 100 steps (both adapt from 0.05 towards ~0.56 at 16
     parameters): equal within the ensemble error plus 1e-3 relative, at every checkpoint."""
