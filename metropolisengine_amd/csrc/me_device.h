@@ -272,16 +272,39 @@ struct EnergyDiag {  // sum a_i x_i^2 + sum b_j |z_j|^2; weights expanded to D e
 };
 
 template <typename R, int NR, int NC>
-struct EnergyDense {  // x^T A x, A[D][D] row-major in device memory; entries are wave-uniform (scalar loads)
+struct EnergyDense {  // x^T A x, A[D][D] row-major in device memory
   static constexpr int D = NR + 2 * NC;
+  static constexpr int PT = D * (D + 1) / 2;
   const R *a;
+  // Only the symmetric part of A matters: E = sum_i x_i (T_ii x_i + sum_{j<i} T_ij x_j) with T_ij = A_ij + A_ji, half the
+  // multiply-adds.  T lives in LDS (prepare(), once per block): every lane reads the SAME address, which LDS serves as a
+  // broadcast.  The first version read A through scalar loads; hipcc hoisted all D*D of them, ran out of SGPRs and the
+  // kernels spilled (D = 16: 120-238 AGPR copies in float32, 0.5-1.8 KB of scratch per lane in float64).
+  static __device__ __forceinline__ R *folded() {
+    __shared__ R t[PT];
+    return t;
+  }
+  __device__ __forceinline__ void prepare() const {
+    R *t = folded();
+    for (int k = threadIdx.x; k < PT; k += blockDim.x) {
+      int i = 0;
+      while ((i + 1) * (i + 2) / 2 <= k) ++i;
+      const int j = k - i * (i + 1) / 2;
+      t[k] = i == j ? a[i * D + i] : a[i * D + j] + a[j * D + i];
+    }
+    __syncthreads();
+  }
   __device__ __forceinline__ R operator()(const R (&x)[D]) const {
+    const R *t = folded();
+    // the reads of T are loop-invariant: hoisted out of the sweep loop they would sit in D(D+1)/2 registers for the whole
+    // launch (136 at D = 16).  The clobber keeps them here, where each lives for one multiply-add.
+    asm volatile("" ::: "memory");
     R e = 0;
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       R y = 0;
 #pragma unroll
-      for (int j = 0; j < D; ++j) y += a[i * D + j] * x[j];
+      for (int j = 0; j <= i; ++j) y += t[i * (i + 1) / 2 + j] * x[j];
       e += x[i] * y;
     }
     return e;
@@ -354,6 +377,14 @@ template <class E, typename R, int D>
 __device__ __forceinline__ bool energy_reject(const E &, const R (&)[D], long) {
   return false;
 }
+
+// An energy may stage read-only data in LDS once per block (EnergyDense); the others have nothing to prepare.
+template <class E>
+__device__ __forceinline__ auto energy_prepare(const E &en, int) -> decltype(en.prepare()) {
+  en.prepare();
+}
+template <class E>
+__device__ __forceinline__ void energy_prepare(const E &, long) {}
 
 // ------------------------------------------------------------------------------------------------ energy ledger
 // The reference caches one energy per term and lets a group move re-evaluate only the terms registered for that group
@@ -476,6 +507,7 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   using N_ = Num<R>;
 
   if constexpr (!INJECT) N_::prepare();
+  energy_prepare(en, 0);
   unsigned int wave_accepted = 0;
   bool bad_energy = false, bad_width = false;
   const long long stride = (long long)gridDim.x * blockDim.x;   // 64 threads per block, or 256 for fused sweeps
@@ -657,6 +689,7 @@ template <typename R, int NR, int NC, class Energy>
 __global__ void __launch_bounds__(kStepThreads) k_init_energy(const R *xs, R *energy, long long n, unsigned int *status,
                                                                 Energy en, int total_row) {
   constexpr int D = NR + 2 * NC;
+  energy_prepare(en, 0);
   const long long stride = (long long)gridDim.x * kStepThreads;
   for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < n; c += stride) {
     R x[D];

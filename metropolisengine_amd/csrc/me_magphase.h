@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(kStepThreads) k_step_magphase(StepArgs<R> a, E
   using N_ = Num<R>;
 
   if constexpr (!INJECT) N_::prepare();
+  energy_prepare(en, 0);
   unsigned int wave_accepted = 0;
   bool bad_energy = false, bad_width = false;
   const long long stride = (long long)gridDim.x * kStepThreads;
