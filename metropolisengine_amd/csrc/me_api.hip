@@ -514,7 +514,9 @@ int me_create(const me_config *c, me_engine **out) {
   if (e->nc == 0) ME_CREATE_HIP(hipMalloc(&e->shared_full, (size_t)e->nr * e->nr * es));
   if (e->shared_full && ks->prepare_matrix) ME_CREATE_HIP(hipMalloc(&e->shared_image, ks->matrix_image_bytes));
   ME_CREATE_HIP(hipMalloc(&e->row_dev, (size_t)std::max(std::max(e->d, e->p), e->nobs) * es));
-  e->n_slots = (e->n + 63) / 64 + 8;   // one slot per wavefront of the largest grid any step kernel uses
+  // one slot per wavefront of the largest grid any step kernel uses: the float64 dense-64 kernel gives a wavefront a tile
+  // of 32 chains (me_dense_f64.h), every other kernel 64
+  e->n_slots = (e->n + 31) / 32 + 8;
   ME_CREATE_HIP(hipMalloc((void **)&e->accept_slots, (size_t)e->n_slots * sizeof(unsigned long long)));
   ME_CREATE_HIP(hipMalloc((void **)&e->accept_total, sizeof(unsigned long long)));
   ME_CREATE_HIP(hipMalloc((void **)&e->status, sizeof(unsigned int)));
