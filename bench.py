@@ -53,12 +53,12 @@ def pmc_traffic(dtype, chains_log2, sweeps):
     return rec.get("traffic_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
 
 
-def issue_utilisation(torch, device, chain_sweeps_per_second):
+def issue_utilisation(torch, device, chain_sweeps_per_second, suffix=""):
     """Fraction of the chip's vector-issue cycles the fused-sweep run occupies (fused sweeps are
     instruction-bound, so this -- not the HBM fraction -- describes them).  Static VALU count of one sweep from the
     newest profiles/r*_kernel_valu.json (tools/valu_count.py); a wave64 instruction holds a SIMD for 4 cycles."""
     import glob
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_valu.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_valu%s.json" % suffix)))
     if not files:
         return None
     with open(files[-1]) as fh:
@@ -189,9 +189,11 @@ def other_configs(me, device, chains_log2):
         except Exception as exc:                        # a side measurement must not sink the headline line
             out["config4" + ("" if dtype == "f32" else "_f64")] = {"error": repr(exc)}
     src = os.path.join(ROOT, "examples", "user_energy_cylinder.h")
-    out["config5"] = protocol(me.MetropolisEngine(me.UserEnergy("cylinder", src, (1.0, 0.5, 1.0)),
-                                                  me.AbsReal0AtLeast(1.0), [0.1, 0.0], [0.05] * 7, temp=0.1,
-                                                  n_chains=n // 4, seed=2026, device=device), n // 4, 10, 100, 60)
+    for dtype in ("f32", "f64"):
+        out["config5" + ("" if dtype == "f32" else "_f64")] = protocol(
+            me.MetropolisEngine(me.UserEnergy("cylinder", src, (1.0, 0.5, 1.0)), me.AbsReal0AtLeast(1.0), [0.1, 0.0],
+                                [0.05] * 7, temp=0.1, n_chains=n // 4, seed=2026, dtype=dtype, device=device),
+            n // 4, 10, 100, 60)
     return out
 
 
@@ -333,6 +335,9 @@ def main():
         launches = max(40, args.steps // args.fused_sweeps)
         fused = side_run(engine, n_local, per_step, args.fused_sweeps, launches)
         fused["dtype"] = args.dtype
+        if args.chains_log2 == 20 and world == 1:
+            # float64 vector instructions take at least 4 cycles like the float32 ones the helper assumes; most take more
+            fused["valu_issue"] = issue_utilisation(torch, local_rank, fused["value"], "_f64" if args.dtype == "f64" else "")
 
     stats = pooled_statistics(engine)                      # the one collective: RCCL all-reduce of pooled moments
     engine.sync()

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import metropolisengine_amd as me
+from metropolisengine_amd import _capi
 from oracle import energies
 from oracle.manychain import ManyChainOracle
 from oracle.reference_chain import adaptation_constants
@@ -175,3 +176,29 @@ def test_split_pooled_moments_report_the_state_at_begin():
     stats = pooled_statistics_end(eng)
     want = moments_to_statistics(later, 2, 1)
     assert np.array_equal(stats["covariance"], want["covariance"])
+
+
+def test_partial_get_set_of_the_tile_major_packed_fields():
+    """ME_FIELD_COV / ME_FIELD_FACTOR are tile-major on the device ([64-chain tile][entry][lane]); me_get / me_set of any
+    chain range -- inside one tile, across tile borders, up to the ragged last tile -- round-trips and leaves every
+    other chain untouched."""
+    n = 64 * 3 + 21
+    a = (1.0, 2.0)
+    eng = me.MetropolisEngine(me.DiagQuadratic(a, a), None, [0.0] * 2, [0j] * 2, temp=1.0, n_chains=n, seed=5, dtype="f64")
+    for _ in range(55):
+        eng.step_all(3)
+        eng.measure()
+    for field in (_capi.FIELD_COV, _capi.FIELD_FACTOR):
+        before = eng._get(field)
+        assert before.shape == (n, 2 * 3 // 2 + 4)
+        for begin, count in ((5, 10), (60, 10), (0, 64), (100, 113), (n - 21, 21), (n - 1, 1)):
+            assert np.array_equal(eng._get(field, begin, count), before[begin:begin + count])
+            new = before[begin:begin + count] + 1.0 + np.arange(count)[:, None]
+            eng._set(field, new, chain_begin=begin)
+            after = eng._get(field)
+            assert np.array_equal(after[begin:begin + count], new)
+            mask = np.ones(n, dtype=bool)
+            mask[begin:begin + count] = False
+            assert np.array_equal(after[mask], before[mask])
+            eng._set(field, before[begin:begin + count], chain_begin=begin)
+        assert np.array_equal(eng._get(field), before)
