@@ -114,3 +114,24 @@ def test_config5_full_size_user_energy_and_wall():
     scale = np.max(np.diag(cov)[2:])
     assert np.all(np.abs(np.diag(cov[re, im])) < 8 * scale * np.sqrt(1.0 / n) + 1e-4)
     assert np.all(np.abs(np.diag(cov)[re] - np.diag(cov)[im]) < 8 * scale * np.sqrt(2.0 / n) + 1e-4)
+
+
+def test_engines_beyond_the_4gib_packed_field_keep_no_per_chain_covariance():
+    """16 real parameters x 2^22 chains in float64: the packed covariance field would be 4.6 GB, past what one buffer
+    descriptor spans.  cov_mode="reference" is refused with a clear message; the fixed / pooled shapes run (this is the
+    engine behind bench.py's `roofline_hbm`) and simply keep no per-chain covariance."""
+    n = 1 << 22
+    with pytest.raises(NotImplementedError, match="4 GiB"):
+        me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 16, None, temp=1.0, n_chains=n, seed=1, dtype="f64")
+    eng = me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 16, None, temp=1.0, n_chains=n, seed=1, dtype="f64",
+                              cov_mode="fixed")
+    eng.step_all(60)
+    for _ in range(3):
+        eng.step_all()
+        eng.measure()
+    with pytest.raises(NotImplementedError):
+        eng.covariance_matrix_real
+    st = moments_to_statistics(eng.pooled_moments(), 16, 0)
+    assert st["n_chains"] == n and 0.2 < st["acceptance_rate"] < 0.95
+    mean = eng._get(_capi.FIELD_MEAN, n - 100, 100)
+    assert np.all(np.isfinite(mean)) and np.any(mean != 0.0)
