@@ -29,7 +29,7 @@ ARCH = "gfx950"
 #   tests and the reference's demos use.  Any other pair is compiled on demand by build_dims().
 KERNEL_DIMS = [
     (1, 0, 0, 1), (2, 0, 1, 1), (3, 0, 0, 1), (4, 0, 1, 1), (8, 0, 0, 1), (16, 0, 1, 1),
-    (64, 0, 1, 0),
+    (64, 0, 1, 2),
     (0, 1, 0, 1), (0, 2, 0, 1), (0, 3, 0, 1), (0, 4, 0, 1),
     (1, 1, 0, 1), (1, 2, 0, 1), (2, 1, 0, 1), (2, 2, 1, 1), (4, 4, 0, 1), (2, 7, 0, 1),
 ]
@@ -181,7 +181,7 @@ def build_dims(n_real, n_complex, force=False):
                            "run on the runtime-dimension kernels of the main library (csrc/me_runtime_dims.hip), no build "
                            "needed" % (MAX_REGISTER_DOF, d))
     defines = ["-DME_NR=%d" % n_real, "-DME_NC=%d" % n_complex, "-DME_DENSE=%d" % int(d <= 24),
-               "-DME_PER_CHAIN=%d" % int(packed <= MAX_PACKED_IN_REGISTERS)]
+               "-DME_PER_CHAIN=%d" % (1 if packed <= MAX_PACKED_IN_REGISTERS else (2 if n_complex == 0 else 0))]
     return _build_plugin(dims_plugin_path(n_real, n_complex), defines, [], force=force)
 
 

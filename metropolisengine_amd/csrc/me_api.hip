@@ -437,11 +437,12 @@ int me_create(const me_config *c, me_engine **out) {
   // per-chain covariance / factor fields are the widest: where THEY would pass 4 GiB and the proposal shape does not
   // need them (ME_COV_FIXED / ME_COV_POOLED) the engine simply keeps no per-chain covariance -- as for parameter
   // spaces without per-chain kernels, the ensemble covariance then comes from me_pooled_moments.
-  bool keep_per_chain = ks->per_chain_cov;
+  // streamed sets (more than 160 packed entries) keep the per-chain matrices only when the proposals need them
+  bool keep_per_chain = ks->per_chain_cov && (!ks->streams_packed || c->cov_mode == ME_COV_REFERENCE);
   {
     const long long esz = c->dtype == ME_F32 ? 4 : 8;
     const long long limit = 1ll << 32;
-    if (keep_per_chain && (long long)packed_total(c->n_real, c->n_complex) * ((c->n_chains + 63) / 64 * 64) * esz >= limit) {
+    if (keep_per_chain && !ks->streams_packed && (long long)packed_total(c->n_real, c->n_complex) * ((c->n_chains + 63) / 64 * 64) * esz >= limit) {
       if (c->cov_mode == ME_COV_REFERENCE)
         return fail(nullptr, ME_ERR_UNSUPPORTED,
                     "the per-chain covariance field would exceed 4 GiB on this engine; shard the chains over more "
@@ -507,7 +508,7 @@ int me_create(const me_config *c, me_engine **out) {
   ME_CREATE_HIP(hipMalloc(&e->width, n * e->width_rows * es));
   ME_CREATE_HIP(hipMalloc(&e->mean, n * e->d * es));
   ME_CREATE_HIP(hipMalloc(&e->obs_mean, n * e->nobs * es));
-  if (keep_per_chain || (!ks->per_chain_cov && ks->tracks_cov && (c->flags & ME_FLAG_TRACK_COVARIANCE)))
+  if (keep_per_chain || ((!ks->per_chain_cov || ks->streams_packed) && ks->tracks_cov && (c->flags & ME_FLAG_TRACK_COVARIANCE)))
     ME_CREATE_HIP(hipMalloc(&e->cov, (n + 63) / 64 * 64 * e->p * es));      // tile-major: whole 64-chain tiles
   if (keep_per_chain) ME_CREATE_HIP(hipMalloc(&e->factor, (n + 63) / 64 * 64 * e->p * es));
   ME_CREATE_HIP(hipMalloc(&e->shared_factor, (size_t)e->p * es));

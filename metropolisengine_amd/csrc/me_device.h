@@ -476,6 +476,13 @@ __host__ __device__ constexpr int cre(int pr, int i, int j) { return pr + i * i 
 __host__ __device__ constexpr int cim(int pr, int i, int j) { return pr + i * i + 2 * j + 1; }
 __host__ __device__ constexpr int cdiag(int pr, int i) { return pr + i * i + 2 * i; }
 
+// LDS home of the normals of a sweep for the streamed-factor proposal (k_step, STREAM_FACTOR)
+template <typename R, int NR>
+__device__ __forceinline__ R (*stream_normals())[kStepThreads] {
+  __shared__ R g[NR][kStepThreads];
+  return g;
+}
+
 // INJECT = true replaces the Philox draws by caller-provided streams (test hook: replays the reference's golden
 // trajectories, tests/golden/, through the very same proposal / accept / adapt code).
 // Tuning knobs (experiments; defaults are the shipped configuration):
@@ -520,7 +527,11 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   const bool stale_total = MIXED && GROUP == GROUP_ALL && a.stale_total != 0;
   constexpr bool PER_CHAIN = CK == CK_PER_CHAIN || CK == CK_PER_CHAIN_NT;
   constexpr int PF = PER_CHAIN ? NR * (NR + 1) / 2 + NC * NC : 0;
-  const TiledField<R> ffac(a.factor, a.n, PF);
+  // per-chain factors beyond the register-resident size are streamed (pure real spaces only; launched with
+  // kStepThreads-wide blocks: the parked normals are sized for them)
+  constexpr bool STREAM_FACTOR = PER_CHAIN && PF > kMaxPackedInRegisters;
+  static_assert(!STREAM_FACTOR || NC == 0, "streamed per-chain factors exist for pure real parameter spaces");
+  const TiledField<R> ffac(a.factor, a.n, STREAM_FACTOR ? 0 : PF);
   for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
     R x[D];
@@ -596,6 +607,35 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
             xp[NR + j] = x[NR + j] + w_c * (g[NR + j] * R(0.70710678118654752440));
             xp[NR + NC + j] = x[NR + NC + j] + w_c * (g[NR + NC + j] * R(0.70710678118654752440));
           }
+        }
+      } else if constexpr (STREAM_FACTOR) {
+        // Packed factors too large for registers (more than 160 entries; pure real spaces, e.g. 64 parameters = 2 080
+        // entries = 8-16 KB per chain and step): the normals are parked in LDS so that the row products can be ROLLED
+        // loops, and each row of L streams through the lane in batches of 16 loads issued ahead of their multiply-adds.
+        // The field may pass the 4 GiB a buffer descriptor spans: a 64-bit pointer walks the chain's tile instead.
+        // (the clobber keeps the 2 080 loop-invariant loads inside the sweep loop: hoisted, they went to 16 KB of scratch)
+        asm volatile("" ::: "memory");
+        R(*gs)[kStepThreads] = stream_normals<R, NR>();
+#pragma unroll
+        for (int j = 0; j < NR; ++j) gs[j][threadIdx.x] = g[j];
+        const R *row = a.factor + (c >> 6) * (long long)PF * 64 + (c & 63);      // tile-major: entries 64 values apart
+        asm volatile("" : "+v"(row));     // opaque per sweep: otherwise 200 derived row addresses are hoisted and spilled
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          R acc = 0;
+          int j = 0;
+#pragma unroll 1
+          for (; j + 16 <= i + 1; j += 16) {
+            R f[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) f[u] = CK == CK_PER_CHAIN_NT ? __builtin_nontemporal_load(row + (j + u) * 64) : row[(j + u) * 64];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += f[u] * gs[j + u][threadIdx.x];
+          }
+#pragma unroll 1
+          for (; j <= i; ++j) acc += (CK == CK_PER_CHAIN_NT ? __builtin_nontemporal_load(row + j * 64) : row[j * 64]) * gs[j][threadIdx.x];
+          xp[i] = x[i] + w_r * acc;
+          row += (i + 1) * 64;
         }
       } else {
         if constexpr (MOVE_REAL) {
@@ -986,6 +1026,88 @@ __global__ void __launch_bounds__(kStepThreads) k_factor(const R *cov, R *factor
     cholesky_packed<R, NR, NC>(m, bad_pivot);
 #pragma unroll
     for (int k = 0; k < P; ++k) packed_store<NT>(ffac, k, toff, m[k]);
+  }
+  if (bad_pivot) atomicOr(status, (unsigned int)ST_BAD_PIVOT);
+}
+
+// Per-chain Cholesky factor of a covariance matrix too large for registers (more than 160 packed entries; pure real
+// spaces): factor = chol(C), row by row (Cholesky-Banachiewicz), each lane its own chain, everything through global
+// memory in the tile-major layout -- L_ij = (C_ij - sum_{k<j} L_ik L_jk) / L_jj.  The row being built lives in LDS
+// ([NR][64 lanes], lane-linear); the finished rows are re-read from the factor field itself, in batches of 16 loads
+// issued ahead of their multiply-adds.  ROWS rows are built together so that every finished L_jk that is loaded serves
+// ROWS dot products: the traffic is NR^3 / (6 ROWS) loads per chain (64 parameters, ROWS = 4: 11 k loads = 44 KB in
+// float32).  Slow by construction -- an order of magnitude above a measure() with the pooled shape -- and there only
+// so that cov_mode="reference" keeps the reference's semantics (metropolis_engine.py:416-421 feeding :268-270) at any
+// size.  The fields may pass 4 GiB: 64-bit pointers.
+template <typename R, int NR, bool NT>
+__global__ void __launch_bounds__(kStepThreads) k_factor_stream(const R *cov, R *factor, unsigned int *status, long long n) {
+  constexpr int P = NR * (NR + 1) / 2;
+  constexpr int ROWS = sizeof(R) == 4 ? 4 : 2;                  // LDS: ROWS x NR x 64 values (64 KiB at NR = 64)
+  using N_ = Num<R>;
+  __shared__ R rows[ROWS][NR][kStepThreads];
+  bool bad_pivot = false;
+  const long long stride = (long long)gridDim.x * kStepThreads;
+  const int lane = threadIdx.x;
+  for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < n; c += stride) {
+    const long long base = (c >> 6) * (long long)P * 64 + (c & 63);
+    const R *cv = cov + base;
+    R *fc = factor + base;
+    for (int i0 = 0; i0 < NR; i0 += ROWS) {
+      const int nrows = NR - i0 < ROWS ? NR - i0 : ROWS;
+      // the covariance rows of the block into LDS
+      for (int r = 0; r < nrows; ++r) {
+        const R *src = cv + (long long)tri(i0 + r, 0) * 64;
+        for (int j = 0; j <= i0 + r; ++j) rows[r][j][lane] = NT ? __builtin_nontemporal_load(src + j * 64) : src[j * 64];
+      }
+      // columns left of the block: every finished row j < i0 serves all rows of the block
+      for (int j = 0; j < i0; ++j) {
+        const R *lj = fc + (long long)tri(j, 0) * 64;
+        R s[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) s[r] = R(0);
+        int k = 0;
+        for (; k + 16 <= j; k += 16) {
+          R f[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) f[u] = lj[(k + u) * 64];
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) s[r] += rows[r][k + u][lane] * f[u];
+        }
+        for (; k < j; ++k) {
+          const R f = lj[k * 64];
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) s[r] += rows[r][k][lane] * f;
+        }
+        const R inv = R(1) / lj[j * 64];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) rows[r][j][lane] = (rows[r][j][lane] - s[r]) * inv;
+      }
+      // the triangle inside the block: rows depend on each other here, everything is in LDS
+      for (int r = 0; r < nrows; ++r) {
+        const int i = i0 + r;
+        for (int j = i0; j < i; ++j) {
+          const int rj = j - i0;
+          R s = R(0);
+          for (int k = 0; k < j; ++k) s += rows[r][k][lane] * rows[rj][k][lane];
+          rows[r][j][lane] = (rows[r][j][lane] - s) / rows[rj][j][lane];
+        }
+        R s = rows[r][i][lane];
+        for (int k = 0; k < i; ++k) s -= rows[r][k][lane] * rows[r][k][lane];
+        if (!(s > R(0))) { bad_pivot = true; s = R(1e-30); }
+        rows[r][i][lane] = N_::sqrt_(s);
+      }
+      // finished rows out
+      for (int r = 0; r < nrows; ++r) {
+        R *dst = fc + (long long)tri(i0 + r, 0) * 64;
+        for (int j = 0; j <= i0 + r; ++j) {
+          if constexpr (NT) __builtin_nontemporal_store(rows[r][j][lane], dst + j * 64);
+          else dst[j * 64] = rows[r][j][lane];
+        }
+      }
+      // the next block reads these rows back through global memory from this same lane: program order suffices
+    }
   }
   if (bad_pivot) atomicOr(status, (unsigned int)ST_BAD_PIVOT);
 }

@@ -117,6 +117,9 @@ struct KernelSet {
   hipError_t (*pool_stage1)(const void *x, long long n, double *partials, int n_rows, hipStream_t);
   // user-energy sets only: the plugin source defines me_user_reject (ME_USER_HAS_REJECT), so ME_REJECT_USER means something
   bool has_user_reject;
+  // per_chain_cov with the packed matrices STREAMED (more than 160 entries, pure real spaces): the covariance and factor
+  // fields are only kept for ME_COV_REFERENCE (or the tracking flag), are walked with 64-bit pointers and may pass 4 GiB
+  bool streams_packed;
 };
 
 void register_kernel_set(const KernelSet *set);

@@ -1,7 +1,9 @@
 // One kernel set per (n_real, n_complex): compiled once per pair with -DME_NR=.. -DME_NC=.. (see build.py), for
 // both device dtypes, and self-registered with the C-ABI layer at load time.
 //   -DME_DENSE=1     also instantiate the dense quadratic-form energy (x^T A x)
-//   -DME_PER_CHAIN=0 omit the per-chain covariance/factor kernels (packed matrix too large for registers)
+//   -DME_PER_CHAIN=0 omit the per-chain covariance/factor kernels
+//   -DME_PER_CHAIN=1 per-chain kernels with the packed matrix in registers (at most 160 entries)
+//   -DME_PER_CHAIN=2 per-chain kernels that STREAM the packed matrix (more than 160 entries; pure real spaces)
 #include <type_traits>
 
 #include "me_device.h"
@@ -195,7 +197,9 @@ hipError_t launch_step_group(const StepLaunch &l, const StepArgs<R> &a, const En
 template <typename R, class Energy>
 hipError_t step_with(const StepLaunch &l, const Energy &en, hipStream_t stream) {
   const StepArgs<R> a = typed<R>(l);
-  const int threads = l.n_sweeps >= kFusedSweepsThreshold ? kFusedStepThreads : kStepThreads;
+  // fused sweeps run in 256-thread blocks; the streamed per-chain factor path parks its normals in LDS sized for 64
+  const bool per_chain = l.cov_kind == CK_PER_CHAIN;
+  const int threads = (l.n_sweeps >= kFusedSweepsThreshold && !(ME_PER_CHAIN == 2 && per_chain)) ? kFusedStepThreads : kStepThreads;
   const dim3 grid(grid_for(l.n, l.grid_blocks, threads)), block(threads);
   if (l.inj_normals) {
     // injected-stream replay: float64 only (it exists to check trajectories against the float64 reference)
@@ -207,6 +211,8 @@ hipError_t step_with(const StepLaunch &l, const Energy &en, hipStream_t stream) 
   // pipe (me_dense_bf16x3.h) or, with METROPOLIS_DENSE64_FP32_MFMA=1, the fp32 MFMA form (me_dense_mfma.h)
   if constexpr (std::is_same<R, float>::value && NR == 64 && NC == 0 &&
                 std::is_same<Energy, EnergyDense<float, 64, 0>>::value) {
+    // per-chain proposal shapes (cov_mode = reference at 64 parameters) take the generic kernel with streamed factors
+    if (per_chain) return launch_step_group<R, Energy, false>(l, a, en, grid, block, stream);
     if (dense64_exact_fp32_mfma()) {
       if (l.cov_kind == CK_IDENTITY)
         return launch_step_dense64_mfma<CK_IDENTITY>(a, en.a, nullptr, l.grid_blocks, stream);
@@ -224,6 +230,7 @@ hipError_t step_with(const StepLaunch &l, const Energy &en, hipStream_t stream) 
   } else if constexpr (std::is_same<R, double>::value && NR == 64 && NC == 0 &&
                        std::is_same<Energy, EnergyDense<double, 64, 0>>::value) {
     // ... and at the reference's precision: v_mfma_f64_16x16x4_f64 on the folded lower triangle (me_dense_f64.h)
+    if (per_chain) return launch_step_group<R, Energy, false>(l, a, en, grid, block, stream);
     if (!l.energy_image) return hipErrorInvalidValue;
     if (l.cov_kind == CK_IDENTITY)
       return launch_step_dense64_f64<CK_IDENTITY>(a, (const double *)l.energy_image, nullptr, l.grid_blocks, stream);
@@ -369,7 +376,7 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
   a.write_factor = l.write_factor;
   // small packed matrices: one fused launch; large ones: streaming update, then the factor kernel (see k_measure)
   constexpr int P = NR * (NR + 1) / 2 + NC * NC;
-  constexpr bool kFused = ME_PER_CHAIN != 0 && P <= ME_MEASURE_FUSED_MAX_P;
+  constexpr bool kFused = ME_PER_CHAIN == 1 && P <= ME_MEASURE_FUSED_MAX_P;
   const dim3 grid(grid_for(l.n, l.grid_blocks)), block(kStepThreads);
   // Cache policy by size (k_measure's comment in me_device.h): the packed fields go non-temporal when the whole working
   // set (x, means, observables, covariance, factor) exceeds the Infinity Cache; the means and observables too when even
@@ -386,12 +393,18 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
     if (ntm) hipLaunchKernelGGL((k_measure<R, NR, NC, false, false, false, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((k_measure<R, NR, NC, false, false, false, false>), grid, block, 0, stream, a);
   }
-#if ME_PER_CHAIN
+#if ME_PER_CHAIN == 1
   if constexpr (!kFused) {
     if (l.update_cov && l.write_factor) {
       if (nt) hipLaunchKernelGGL((k_factor<R, NR, NC, true>), grid, block, 0, stream, (const R *)l.cov, (R *)l.factor, l.status, l.n);
       else hipLaunchKernelGGL((k_factor<R, NR, NC, false>), grid, block, 0, stream, (const R *)l.cov, (R *)l.factor, l.status, l.n);
     }
+  }
+#elif ME_PER_CHAIN == 2
+  static_assert(NC == 0 && P > kMaxPackedInRegisters, "ME_PER_CHAIN=2 is for pure real spaces with more than 160 packed entries");
+  if (l.cov && l.update_cov && l.write_factor) {
+    if (nt) hipLaunchKernelGGL((k_factor_stream<R, NR, true>), grid, block, 0, stream, (const R *)l.cov, (R *)l.factor, l.status, l.n);
+    else hipLaunchKernelGGL((k_factor_stream<R, NR, false>), grid, block, 0, stream, (const R *)l.cov, (R *)l.factor, l.status, l.n);
   }
 #endif
   return hipGetLastError();
@@ -438,11 +451,11 @@ constexpr bool kHasUserReject = true;
 constexpr bool kHasUserReject = false;
 #endif
 const KernelSet kSetF32 = {ME_SET_NAME, ME_F32, NR, NC, ME_PER_CHAIN != 0, (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0), has_energy, energy_terms, step<float>,
-                           (NC > 0 && ME_PER_CHAIN) ? magphase<float> : nullptr, measure<float>, init_energy<float>,
-                           ME_PREPARE_MATRIX_F32, kHasUserReject};
+                           (NC > 0 && ME_PER_CHAIN == 1) ? magphase<float> : nullptr, measure<float>, init_energy<float>,
+                           ME_PREPARE_MATRIX_F32, kHasUserReject, ME_PER_CHAIN == 2};
 const KernelSet kSetF64 = {ME_SET_NAME, ME_F64, NR, NC, ME_PER_CHAIN != 0, (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0), has_energy, energy_terms, step<double>,
-                           (NC > 0 && ME_PER_CHAIN) ? magphase<double> : nullptr, measure<double>, init_energy<double>,
-                           ME_PREPARE_MATRIX_F64, kHasUserReject};
+                           (NC > 0 && ME_PER_CHAIN == 1) ? magphase<double> : nullptr, measure<double>, init_energy<double>,
+                           ME_PREPARE_MATRIX_F64, kHasUserReject, ME_PER_CHAIN == 2};
 
 struct Registrar {
   Registrar() {

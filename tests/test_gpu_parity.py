@@ -324,10 +324,11 @@ def test_pooled_shared_covariance_mode():
 
 
 def test_errors_on_gpu():
-    with pytest.raises(RuntimeError):
-        me.MetropolisEngine(me.IsoQuadratic(), initial_real_params=[0.0] * 100, temp=1.0)      # beyond register kernels
-    with pytest.raises(NotImplementedError):
-        me.MetropolisEngine(me.IsoQuadratic(), initial_real_params=[0.0] * 64, temp=1.0)       # needs cov_mode fixed
+    with pytest.raises(NotImplementedError, match="identity proposal shape"):
+        me.MetropolisEngine(me.IsoQuadratic(), initial_real_params=[0.0] * 100, temp=1.0)      # runtime-dimension kernels:
+    #                                                                                            cov_mode="fixed" only
+    ref = me.MetropolisEngine(me.IsoQuadratic(), initial_real_params=[0.0] * 64, temp=1.0, n_chains=64)   # streamed per-chain
+    assert ref.covariance_matrix_real.shape == (64, 64, 64)                                              # shapes (reference mode)
     eng = me.MetropolisEngine(me.IsoQuadratic(), initial_real_params=[0.0] * 64, temp=1.0, cov_mode="fixed",
                               n_chains=256)
     eng.step_all(3)

@@ -10,7 +10,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 nr, nc = sys.argv[1], sys.argv[2]
 extra = sys.argv[3:]
 cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(root, "include"),
-       "-DME_NR=" + nr, "-DME_NC=" + nc, "-DME_DENSE=1", "-DME_PER_CHAIN=" + ("0" if int(nr) > 32 else "1")] + extra + \
+       "-DME_NR=" + nr, "-DME_NC=" + nc, "-DME_DENSE=1", "-DME_PER_CHAIN=" + ("2" if int(nr) > 17 and int(nc) == 0 else ("0" if int(nr) > 32 else "1"))] + extra + \
       ["-c", os.path.join(root, "metropolisengine_amd/csrc/me_kernels.hip"), "-o", "/tmp/kres.o",
        "-Rpass-analysis=kernel-resource-usage"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
