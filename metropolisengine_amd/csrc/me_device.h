@@ -611,7 +611,8 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
       } else if constexpr (STREAM_FACTOR) {
         // Packed factors too large for registers (more than 160 entries; pure real spaces, e.g. 64 parameters = 2 080
         // entries = 8-16 KB per chain and step): the normals are parked in LDS so that the row products can be ROLLED
-        // loops, and each row of L streams through the lane in batches of 16 loads issued ahead of their multiply-adds.
+        // loops, and each row of L streams through the lane in batches of 16 loads issued ahead of their multiply-adds (32 per
+        // batch made hipcc trade registers for scratch).
         // The field may pass the 4 GiB a buffer descriptor spans: a 64-bit pointer walks the chain's tile instead.
         // (the clobber keeps the 2 080 loop-invariant loads inside the sweep loop: hoisted, they went to 16 KB of scratch)
         asm volatile("" ::: "memory");
@@ -1033,8 +1034,8 @@ __global__ void __launch_bounds__(kStepThreads) k_factor(const R *cov, R *factor
 // Per-chain Cholesky factor of a covariance matrix too large for registers (more than 160 packed entries; pure real
 // spaces): factor = chol(C), row by row (Cholesky-Banachiewicz), each lane its own chain, everything through global
 // memory in the tile-major layout -- L_ij = (C_ij - sum_{k<j} L_ik L_jk) / L_jj.  The row being built lives in LDS
-// ([NR][64 lanes], lane-linear); the finished rows are re-read from the factor field itself, in batches of 16 loads
-// issued ahead of their multiply-adds.  ROWS rows are built together so that every finished L_jk that is loaded serves
+// ([NR][64 lanes], lane-linear); the finished rows are re-read from the factor field itself, in batches of 32 (then 8)
+// loads issued ahead of their multiply-adds.  ROWS rows are built together so that every finished L_jk that is loaded serves
 // ROWS dot products: the traffic is NR^3 / (6 ROWS) loads per chain (64 parameters, ROWS = 4: 11 k loads = 44 KB in
 // float32).  Slow by construction -- an order of magnitude above a measure() with the pooled shape -- and there only
 // so that cov_mode="reference" keeps the reference's semantics (metropolis_engine.py:416-421 feeding :268-270) at any
@@ -1057,7 +1058,15 @@ __global__ void __launch_bounds__(kStepThreads) k_factor_stream(const R *cov, R 
       // the covariance rows of the block into LDS
       for (int r = 0; r < nrows; ++r) {
         const R *src = cv + (long long)tri(i0 + r, 0) * 64;
-        for (int j = 0; j <= i0 + r; ++j) rows[r][j][lane] = NT ? __builtin_nontemporal_load(src + j * 64) : src[j * 64];
+        int j = 0;
+        for (; j + 16 <= i0 + r + 1; j += 16) {
+          R v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = NT ? __builtin_nontemporal_load(src + (j + u) * 64) : src[(j + u) * 64];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) rows[r][j + u][lane] = v[u];
+        }
+        for (; j <= i0 + r; ++j) rows[r][j][lane] = NT ? __builtin_nontemporal_load(src + j * 64) : src[j * 64];
       }
       // columns left of the block: every finished row j < i0 serves all rows of the block
       for (int j = 0; j < i0; ++j) {
@@ -1066,12 +1075,21 @@ __global__ void __launch_bounds__(kStepThreads) k_factor_stream(const R *cov, R 
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) s[r] = R(0);
         int k = 0;
-        for (; k + 16 <= j; k += 16) {
-          R f[16];
+        for (; k + 32 <= j; k += 32) {
+          R f[32];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) f[u] = lj[(k + u) * 64];
+          for (int u = 0; u < 32; ++u) f[u] = lj[(k + u) * 64];
 #pragma unroll
-          for (int u = 0; u < 16; ++u)
+          for (int u = 0; u < 32; ++u)
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) s[r] += rows[r][k + u][lane] * f[u];
+        }
+        for (; k + 8 <= j; k += 8) {
+          R f[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) f[u] = lj[(k + u) * 64];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) s[r] += rows[r][k + u][lane] * f[u];
         }
