@@ -98,11 +98,12 @@ typedef enum me_field {
 
 /* me_config.flags */
 typedef enum me_flags {
-  ME_FLAG_TRACK_COVARIANCE = 1, /* parameter spaces whose per-chain matrix is too large for the factor kernels (more
-                                  than 160 packed entries, e.g. 64 real parameters) keep means and observables only
-                                  by default; with this flag measure() also maintains each chain's running covariance
-                                  (metropolis_engine.py:416-427) as statistics -- P*4 bytes per chain, read and
-                                  written once per measure().  Smaller spaces always track it. */
+  ME_FLAG_TRACK_COVARIANCE = 1, /* parameter spaces whose per-chain matrix is too large for registers (more than 160
+                                  packed entries, e.g. 64 real parameters) keep it only where the proposals need it
+                                  (ME_COV_REFERENCE, pure real spaces: streamed kernels); with ME_COV_FIXED / ME_COV_POOLED
+                                  they keep means and observables only.  With this flag measure() also maintains each
+                                  chain's running covariance (metropolis_engine.py:416-427) there, as statistics -- P values
+                                  per chain, read and written once per measure().  Smaller spaces always track it. */
   ME_FLAG_REFERENCE_ENERGY_LEDGERS = 2 /* reproduce the reference's TWO energy ledgers: step_all of a
                                   mixed engine compares against and updates `energy_total` only (metropolis_engine.py:
                                   252-255), group steps compare against and update `energy[term]` only (:214-221,

@@ -145,8 +145,9 @@ class MetropolisEngine:
             raise ValueError("cov_mode must be one of %s" % sorted(_COV_MODES))
         cfg.cov_mode = _COV_MODES[cov_mode]
         self.cov_mode = cov_mode
-        # parameter spaces beyond the factor kernels (> 160 packed matrix entries, e.g. 64 real parameters) keep the
-        # per-chain running covariance only on request: P floats per chain, read and written once per measure()
+        # parameter spaces whose packed matrix is too large for registers (> 160 entries, e.g. 64 real parameters) keep
+        # the per-chain matrices only where the proposals need them (cov_mode="reference": streamed kernels, pure real
+        # spaces) or on request (track_covariance=True: statistics only)
         self.reference_energy_ledgers = bool(reference_energy_ledgers)
         cfg.flags = ((_capi.FLAG_TRACK_COVARIANCE if track_covariance else 0) |
                      (_capi.FLAG_REFERENCE_ENERGY_LEDGERS if reference_energy_ledgers else 0))
