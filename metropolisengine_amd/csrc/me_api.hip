@@ -525,9 +525,10 @@ int me_create(const me_config *c, me_engine **out) {
   ME_CREATE_HIP(hipHostMalloc((void **)&e->host_scratch, 64, hipHostMallocDefault));
   e->host_scratch[0] = e->host_scratch[1] = 0;
   ME_CREATE_HIP(hipHostMalloc((void **)&e->pool_host, sizeof(double) * (size_t)moments_size(e->nr, e->nc), hipHostMallocDefault));
-  ME_CREATE_HIP(hipMalloc((void **)&e->pool_partials,
-                          sizeof(double) * (size_t)pool_reduce_blocks(e->n, e->nr, e->nc) *
-                              (size_t)(1 + e->d + e->nr + e->nc + e->d * (e->d + 1) / 2)));
+  if (pool_reduce_supported(e->nr, e->nc, e->dtype))     // (very large parameter spaces have no pooled-moment kernel)
+    ME_CREATE_HIP(hipMalloc((void **)&e->pool_partials,
+                            sizeof(double) * (size_t)pool_reduce_blocks(e->n, e->nr, e->nc) *
+                                (size_t)(1 + e->d + e->nr + e->nc + e->d * (e->d + 1) / 2)));
   ME_CREATE_HIP(hipMemsetAsync(e->accept_slots, 0, (size_t)e->n_slots * sizeof(unsigned long long), e->stream));
   ME_CREATE_HIP(hipMemsetAsync(e->status, 0, sizeof(unsigned int), e->stream));
   if (ks->n_real < 0 && e->energy_kind == ME_ENERGY_DIAG_QUAD) {
@@ -1006,6 +1007,7 @@ namespace {
 int enqueue_pooled_moments(me_engine *e, void *device_out, int64_t n_doubles) {
   if (n_doubles != moments_size(e->nr, e->nc)) return fail(e, ME_ERR_INVALID, "wrong pooled-moment buffer length");
   if (e->pool_pending) return fail(e, ME_ERR_STATE, "a pooled-moment reduction is in flight (me_pooled_moments_end first)");
+  if (!e->pool_partials) return fail(e, ME_ERR_UNSUPPORTED, "pooled moments: dimension too large for the reduction kernel");
   ME_HIP(e, hipSetDevice(e->device));
   hipError_t err = launch_pool_reduce(e->x, e->n, e->nr, e->nc, e->dtype, e->accept_slots, e->n_slots,
                                       (double)e->proposed, e->pool_partials, (double *)device_out, e->stream,

@@ -270,6 +270,15 @@ hipError_t launch_sum_slots(const unsigned long long *slots, long long n_slots, 
   return hipGetLastError();
 }
 
+// whether launch_pool_reduce can handle these dimensions (entry count and the LDS tile of the first stage)
+bool pool_reduce_supported(int nr, int nc, int dtype) {
+  const int d = nr + 2 * nc;
+  const int n_aug = d + nr + nc;
+  const long long n_entries = 1 + n_aug + (long long)d * (d + 1) / 2;
+  const size_t elem = dtype == ME_F32 ? sizeof(float) : sizeof(double);
+  return n_entries <= (long long)kMaxEntries * kBlockThreads && (size_t)n_aug * kTilePitch * elem <= 160 * 1024;
+}
+
 int pool_reduce_blocks(long long n, int nr, int nc) {
   const int d = nr + 2 * nc;
   const long long n_entries = 1 + d + nr + nc + (long long)d * (d + 1) / 2;

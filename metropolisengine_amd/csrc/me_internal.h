@@ -142,6 +142,8 @@ hipError_t launch_pool_reduce(const void *x, long long n, int n_real, int n_comp
                               hipError_t (*stage1)(const void *, long long, double *, int, hipStream_t) = nullptr);
 // blocks of the first reduction stage; partials must hold pool_reduce_blocks(...) * (1 + D + nr + nc + D(D+1)/2) doubles
 int pool_reduce_blocks(long long n, int n_real, int n_complex);
+// false: the dimensions are beyond the pooled-moment kernels (me_pooled_moments then returns ME_ERR_UNSUPPORTED)
+bool pool_reduce_supported(int n_real, int n_complex, int dtype);
 // Time-series row of the traced chains (chain t*stride, t < n_traced): out[col][t] as doubles with columns
 // [params (d) | energy terms (n_terms) | widths (width_rows)]  -- what measure() appends in the reference (:350-356).
 hipError_t launch_trace(const void *x, const void *energy, const void *width, long long n, int d, int n_terms,
