@@ -188,6 +188,19 @@ def other_configs(me, device, chains_log2):
             del e4
         except Exception as exc:                        # a side measurement must not sink the headline line
             out["config4" + ("" if dtype == "f32" else "_f64")] = {"error": repr(exc)}
+    # config 4's parameter space with the REFERENCE's semantics (every chain its own adaptive 64 x 64 shape, streamed
+    # kernels): what BASELINE's "identity and pooled_shared" prescription avoids, timed so that its cost is on record
+    try:
+        e4 = me.MetropolisEngine(me.DenseQuadratic(m @ m.T / 64 + np.identity(64)), None, [0.0] * 64, None, temp=1.0,
+                                 n_chains=n // 8, seed=2026, cov_mode="reference", dtype="f32", device=device)
+        for _ in range(52):
+            e4.step_all()
+            e4.measure()
+        out["config4_reference_shapes"] = protocol(e4, n // 8, 10, 5, 0)
+        out["config4_reference_shapes"]["dtype"] = "f32"
+        del e4
+    except Exception as exc:
+        out["config4_reference_shapes"] = {"error": repr(exc)}
     src = os.path.join(ROOT, "examples", "user_energy_cylinder.h")
     for dtype in ("f32", "f64"):
         out["config5" + ("" if dtype == "f32" else "_f64")] = protocol(

@@ -130,6 +130,7 @@ struct me_engine {
   double temp = 0, target_acceptance = 0.3, alpha = 0, ratio = 0, reject_bound = 0;
   int m = 0, energy_kind = 0, reject_kind = 0, cov_mode = 0;
   bool stale_total = false;          // ME_FLAG_REFERENCE_ENERGY_LEDGERS on a mixed engine: ledger row n_terms = energy_total
+  hipEvent_t time_start = nullptr, time_stop = nullptr;   // me_time_steps
   std::vector<double> shared_host;   // the packed factor last given to me_set_shared_factor (empty: none); checkpoints
   int cov_kind = CK_IDENTITY;
   int grid_blocks = 0;
@@ -343,6 +344,8 @@ void release(me_engine *e) {
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   if (e->pool_host) (void)hipHostFree(e->pool_host);
   if (e->host_scratch) (void)hipHostFree(e->host_scratch);
+  if (e->time_start) (void)hipEventDestroy(e->time_start);
+  if (e->time_stop) (void)hipEventDestroy(e->time_stop);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -1111,19 +1114,18 @@ int me_time_steps(me_engine *e, int32_t n_launches, int32_t n_sweeps, float *ela
   if (!e || !elapsed_ms) return ME_ERR_INVALID;
   if (n_launches <= 0 || n_sweeps <= 0) return fail(e, ME_ERR_INVALID, "n_launches and n_sweeps must be positive");
   ME_HIP(e, hipSetDevice(e->device));
-  hipEvent_t start, stop;
-  ME_HIP(e, hipEventCreate(&start));
-  ME_HIP(e, hipEventCreate(&stop));
+  // the two events live with the engine: creating and destroying them per call cost ~20 us of a short timed region
+  if (!e->time_start) {
+    ME_HIP(e, hipEventCreate(&e->time_start));
+    ME_HIP(e, hipEventCreate(&e->time_stop));
+  }
+  hipEvent_t start = e->time_start, stop = e->time_stop;
   ME_HIP(e, hipEventRecord(start, e->stream));
   for (int i = 0; i < n_launches; ++i) {
     StepLaunch l;
     fill_step_launch(e, l, n_sweeps);
     hipError_t err = e->ks->step(l, e->stream);
-    if (err != hipSuccess) {
-      (void)hipEventDestroy(start);
-      (void)hipEventDestroy(stop);
-      return fail(e, ME_ERR_HIP, std::string("step launch: ") + hipGetErrorString(err));
-    }
+    if (err != hipSuccess) return fail(e, ME_ERR_HIP, std::string("step launch: ") + hipGetErrorString(err));
     e->step_index += (unsigned long long)n_sweeps;
     e->proposed += (unsigned long long)e->n * (unsigned long long)n_sweeps;
     e->widths_synced = true;
@@ -1131,8 +1133,6 @@ int me_time_steps(me_engine *e, int32_t n_launches, int32_t n_sweeps, float *ela
   ME_HIP(e, hipEventRecord(stop, e->stream));
   ME_HIP(e, hipEventSynchronize(stop));
   ME_HIP(e, hipEventElapsedTime(elapsed_ms, start, stop));
-  (void)hipEventDestroy(start);
-  (void)hipEventDestroy(stop);
   return ME_OK;
 }
 
