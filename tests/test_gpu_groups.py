@@ -192,3 +192,49 @@ def test_f32_group_stepping_is_a_valid_sampler():
         assert np.all(np.abs(var / want - 1) < 6 * np.sqrt(2.0 / n)), (method, var / want)
         widths = eng._get(2)
         assert widths.shape == (n, 3) and not np.allclose(widths[:, 1], widths[:, 2])   # the group widths decouple
+
+
+def test_shared_factor_mixed_engine_follows_the_oracle():
+    """cov_mode="pooled" on a mixed engine: ONE proposal shape for all chains, a real Cholesky factor and the factor of
+    conj(K) for the complex block (metropolis_engine.py:261-302 with the quirk-Q3 convention), installed with
+    set_shared_factor; step_all and group steps follow the oracle run with the same fixed covariance matrices."""
+    from metropolisengine_amd.distributed import pooled_factor
+    nr, nc, n, seed = 2, 2, 150, 71
+    rng = np.random.default_rng(12)
+    br = rng.standard_normal((nr, nr))
+    c_r = br @ br.T + 0.5 * np.identity(nr)
+    bc = rng.standard_normal((nc, nc)) + 1j * rng.standard_normal((nc, nc))
+    k_c = bc @ bc.conj().T + 0.5 * np.identity(nc)                      # Hermitian positive definite, off-diagonal phase
+    cov = np.zeros((nr + 2 * nc, nr + 2 * nc))                          # real representation of (c_r, k_c)
+    a, b = slice(nr, nr + nc), slice(nr + nc, nr + 2 * nc)
+    cov[:nr, :nr] = c_r
+    cov[a, a] = cov[b, b] = k_c.real / 2
+    cov[b, a] = k_c.imag / 2
+    cov[a, b] = -k_c.imag / 2
+    spec = me.DiagQuadratic((1.0, 2.0), (1.5, 3.0))
+    eng = me.MetropolisEngine(spec, None, [0.1, -0.1], [0.2 + 0.1j, -0.1 + 0.3j], temp=1.0, n_chains=n, seed=seed, dtype="f64",
+                              cov_mode="pooled", sampling_width=0.2)
+    eng.set_shared_factor(pooled_factor(cov, nr, nc))
+    ora = ManyChainOracle(nr, nc, energies.diag_quadratic(nr, nc, (1.0, 2.0), (1.5, 3.0)), n, seed=seed, temp=1.0,
+                          initial_real_params=[0.1, -0.1], initial_complex_params=[0.2 + 0.1j, -0.1 + 0.3j],
+                          sampling_width=0.2, covariance_matrix_real=c_r, covariance_matrix_complex=k_c, adapt_shape=False)
+    for cycle in range(25):
+        for op in ("all", "real", "complex", "all"):
+            if op == "all":
+                eng.step_all(2)
+                ora.step(2, group="all")
+            elif op == "real":
+                eng.step_real_group()
+                ora.step(1, group="real")
+            else:
+                eng.step_complex_group()
+                ora.step(1, group="complex")
+        eng.measure()
+        ora.measure()
+    assert np.allclose(eng._get(0), ora.x, rtol=0, atol=TOL)
+    assert np.allclose(eng.energy_total, ora.energy, rtol=0, atol=TOL)
+    assert np.allclose(eng.real_group_sampling_width, ora.width_real, rtol=0, atol=TOL)
+    assert np.allclose(eng.complex_group_sampling_width, ora.width_complex, rtol=0, atol=TOL)
+    assert np.allclose(eng._get(3), ora.mean, rtol=0, atol=TOL)
+    assert eng.accept_stats() == (ora.accepted, ora.proposed)
+    assert 0.05 < ora.accepted / ora.proposed < 0.9
