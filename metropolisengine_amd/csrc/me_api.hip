@@ -418,11 +418,21 @@ int me_create(const me_config *c, me_engine **out) {
     return fail(nullptr, ME_ERR_UNSUPPORTED,
                 "ME_REJECT_USER: this user-energy plugin defines no me_user_reject (#define ME_USER_HAS_REJECT in its source)");
   if (ks->n_real < 0) {   // the runtime-dimension kernel set (me_runtime_dims.hip)
-    if (c->cov_mode != ME_COV_FIXED)
+    if (c->cov_mode == ME_COV_REFERENCE || (c->cov_mode == ME_COV_POOLED && c->n_complex > 0))
       return fail(nullptr, ME_ERR_UNSUPPORTED,
                   "parameter spaces beyond " + std::to_string(kMaxRegisterDof) + " real degrees of freedom run with the "
-                  "identity proposal shape only: use ME_COV_FIXED (cov_mode=\"fixed\"); the ensemble covariance comes from "
-                  "me_pooled_moments");
+                  "identity proposal shape (ME_COV_FIXED, cov_mode=\"fixed\") or, pure real spaces, one shared factor "
+                  "(ME_COV_POOLED); per-chain shapes are not available there");
+    {
+      // a dense energy needs all of x' at once, a shared factor all of g: both are parked in LDS, 64 lanes x D values each
+      const long long per_block = (long long)(c->n_real + 2 * c->n_complex) * 64 * (c->dtype == ME_F32 ? 4 : 8);
+      const bool dense = c->energy_kind == ME_ENERGY_DENSE_QUAD, pooled = c->cov_mode == ME_COV_POOLED;
+      if ((dense || pooled) && per_block * (pooled ? 2 : 1) > 150 * 1024)
+        return fail(nullptr, ME_ERR_UNSUPPORTED,
+                    "a dense quadratic form or a shared proposal factor beyond " + std::to_string(kMaxRegisterDof) +
+                        " degrees of freedom is staged in LDS: this many parameters do not fit (float64: about 290 with the "
+                        "identity shape, 145 with a shared factor; float32 twice that)");
+    }
     if (c->flags & ME_FLAG_REFERENCE_ENERGY_LEDGERS)
       return fail(nullptr, ME_ERR_UNSUPPORTED, "ME_FLAG_REFERENCE_ENERGY_LEDGERS is not available beyond " +
                                                    std::to_string(kMaxRegisterDof) + " real degrees of freedom");
@@ -549,6 +559,23 @@ int me_create(const me_config *c, me_engine **out) {
     ME_CREATE_HIP(hipMalloc(&e->coef_dev, bytes.size()));
     ME_CREATE_HIP(hipMemcpy(e->coef_dev, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
   }
+  if (ks->n_real < 0 && e->energy_kind == ME_ENERGY_DENSE_QUAD) {
+    // the runtime-dimension kernels read the FOLDED lower triangle T_ij = A_ij + A_ji (i > j), T_ii = A_ii, row-major
+    if ((int)e->coef.size() != e->d * e->d) {
+      g_create_error = "wrong number of energy coefficients for this energy kind";
+      release(e);
+      return ME_ERR_INVALID;
+    }
+    std::vector<double> folded;
+    folded.reserve((size_t)e->d * (e->d + 1) / 2);
+    for (int i = 0; i < e->d; ++i)
+      for (int j = 0; j <= i; ++j)
+        folded.push_back(i == j ? e->coef[(size_t)i * e->d + i] : e->coef[(size_t)i * e->d + j] + e->coef[(size_t)j * e->d + i]);
+    std::vector<unsigned char> bytes;
+    to_device_type(folded.data(), folded.size(), e->dtype, bytes);
+    ME_CREATE_HIP(hipMalloc(&e->coef_dev, bytes.size()));
+    ME_CREATE_HIP(hipMemcpy(e->coef_dev, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+  } else
   if (e->energy_kind == ME_ENERGY_DENSE_QUAD || (is_user_kind(e->energy_kind) && !e->coef.empty())) {
     std::vector<unsigned char> bytes;
     to_device_type(e->coef.data(), e->coef.size(), e->dtype, bytes);

@@ -12,15 +12,25 @@
 //                    sweep, paid for with drawing the normals twice.
 //   k_measure_runtime, k_init_energy_runtime: the same loops over d for the running means / observables / energy.
 //
-// Supported: separable energies (ME_ENERGY_ISO_QUAD, ME_ENERGY_DIAG_QUAD), the identity proposal shape (ME_COV_FIXED),
-// the built-in wall, step_all and group-wise steps of mixed engines.  The word layout of a step is the one of every
+//   k_step_runtime_lds  what cannot stream: a DENSE quadratic form needs all of x' at once, a SHARED proposal factor all of
+//                    g.  Both are parked in LDS ([D][64 lanes], one wavefront per block), the folded triangle of A
+//                    (T_ij = A_ij + A_ji) and the packed factor L are read through wave-uniform (scalar) loads, and the
+//                    two O(D^2) products are rolled loops.  Limits: the LDS a block may use (D <= ~290 in float64 with
+//                    the identity shape, ~145 with a shared factor; twice that in float32).
+//
+// Supported: ME_ENERGY_ISO_QUAD, ME_ENERGY_DIAG_QUAD (streamed), ME_ENERGY_DENSE_QUAD (LDS); the identity proposal
+// shape (ME_COV_FIXED) and, for pure real spaces, one shared factor (ME_COV_POOLED); the built-in wall, step_all and
+// group-wise steps of mixed engines.  The word layout of a step is the one of every
 // other kernel (oracle/philox.py): normal i belongs to coordinate i, word 2 ceil(D/2) is the accept uniform.
 #include <type_traits>
 
 #include "me_device.h"
+#include "me_per_device.h"
 
 namespace me {
 namespace {
+
+constexpr size_t kRuntimeLdsLimit = 150 * 1024;      // dynamic LDS a block of the LDS-resident step kernel may ask for
 
 template <typename R>
 struct RuntimeStep {
@@ -176,7 +186,136 @@ __global__ void __launch_bounds__(kBlockThreads) k_init_energy_runtime(const R *
   }
 }
 
-bool has_energy(int kind) { return kind == ME_ENERGY_ISO_QUAD || kind == ME_ENERGY_DIAG_QUAD; }
+// Everything that needs the whole proposal (dense energy) or all normals (shared factor): see the header comment.
+// `folded`: D(D+1)/2 values T_ij (i >= j) for ME_ENERGY_DENSE_QUAD; `factor`: the packed shared factor (pure real
+// spaces: the lower triangle of L, row-major) for CK_SHARED.  Dynamic LDS: xp[D][64] (+ g[D][64] with a factor).
+template <typename R, bool SHARED>
+__global__ void __launch_bounds__(kStepThreads) k_step_runtime_lds(StepArgs<R> a, RuntimeStep<R> p, const R *__restrict__ folded) {
+  using N_ = Num<R>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_rt[];
+  const int nr = p.nr, nc = p.nc, D = nr + 2 * nc;
+  R(*xp)[kStepThreads] = reinterpret_cast<R(*)[kStepThreads]>(smem_rt);
+  R(*gs)[kStepThreads] = xp + D;                                   // SHARED only
+  N_::prepare();
+  const int NW = 2 * ((D + 1) / 2);
+  const bool mixed = nr > 0 && nc > 0;
+  const int d0 = p.group == GROUP_COMPLEX ? nr : 0, d1 = p.group == GROUP_REAL ? nr : D;
+  unsigned int wave_accepted = 0;
+  bool bad_energy = false, bad_width = false;
+  const long long stride = (long long)gridDim.x * kStepThreads, n = a.n;
+  const int lane = threadIdx.x;
+  for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < n; c += stride) {
+    R *xc = a.x + c;
+    R e = a.energy[c];
+    const int wrow = mixed ? p.group : 0;
+    R w = a.width[(long long)wrow * n + c];
+    R w_r = w, w_c = w;
+    if (mixed && p.group == GROUP_ALL && a.split_widths) {
+      w_r = a.width[(long long)GROUP_REAL * n + c];
+      w_c = a.width[(long long)GROUP_COMPLEX * n + c];
+    }
+    const unsigned long long gid = a.chain_offset + (unsigned long long)c;
+    for (int s = 0; s < a.n_sweeps; ++s) {
+      const unsigned long long step = a.step_index + (unsigned long long)s;
+      auto block_of = [&](int b) {
+        U4 ctr;
+        ctr.x = (uint32_t)gid;
+        ctr.y = (uint32_t)(gid >> 32);
+        ctr.z = (uint32_t)step;
+        ctr.w = ((uint32_t)(step >> 32) << 16) | (uint32_t)b;
+        return philox4x32_10(ctr, a.seed_lo, a.seed_hi);
+      };
+      const R s_r = w_r, s_c = w_c * R(0.70710678118654752440);
+      // ---- the normals: straight into x' (identity shape) or parked (shared factor)
+      for (int b = 0; 4 * b < NW; ++b) {
+        const U4 o = block_of(b);
+        R g[4];
+        N_::normal_pair(o.x, o.y, g[0], g[1]);
+        N_::normal_pair(o.z, o.w, g[2], g[3]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int d = 4 * b + t;
+          if (d < D) {
+            if constexpr (SHARED) gs[d][lane] = g[t];
+            else {
+              const R xd = xc[(long long)d * n];
+              xp[d][lane] = (d >= d0 && d < d1) ? fma_(d < nr ? s_r : s_c, g[t], xd) : xd;
+            }
+          }
+        }
+      }
+      if constexpr (SHARED) {
+        // x' = x + w L g, row by row; L packed lower triangle, wave-uniform reads (pure real spaces: nc == 0)
+        const R *lrow = a.factor;
+        for (int i = 0; i < D; ++i) {
+          R acc = R(0);
+          for (int j = 0; j <= i; ++j) acc += lrow[j] * gs[j][lane];
+          xp[i][lane] = fma_(s_r, acc, xc[(long long)i * n]);
+          lrow += i + 1;
+        }
+      }
+      // ---- energy of the proposal
+      R e_new = R(0);
+      if (p.energy_kind == ME_ENERGY_DENSE_QUAD) {
+        const R *trow = folded;
+        for (int i = 0; i < D; ++i) {
+          R y = R(0);
+          for (int j = 0; j <= i; ++j) y += trow[j] * xp[j][lane];
+          e_new += xp[i][lane] * y;
+          trow += i + 1;
+        }
+      } else {
+        for (int d = 0; d < D; ++d) e_new += weight_of(p, d) * xp[d][lane] * xp[d][lane];
+      }
+      const U4 ow = block_of(NW >> 2);
+      const R u = N_::unit((NW & 3) == 0 ? ow.x : ow.z);
+      bool rejected = false;
+      if (a.reject_kind == ME_REJECT_ABS_REAL0_GE) rejected = !(N_::abs_(xp[0][lane]) < a.reject_bound);
+      const R diff = e_new - e;
+      bool accept = diff <= R(0);
+      if (a.temp > R(0)) accept = accept || N_::uphill(u, diff, a.inv_temp, a.inv_temp_log2e);
+      accept = accept && !rejected;
+      bad_energy |= (!rejected && !N_::finite(e_new));
+      if (accept)
+        for (int d = d0; d < d1; ++d) xc[(long long)d * n] = xp[d][lane];
+      e = accept ? e_new : e;
+      w = N_::adapt(w, accept, a.ratio, a.p, a.damping, a.up, a.down);
+      if (p.group == GROUP_ALL) w_r = w_c = w;
+      else if (p.group == GROUP_REAL) w_r = w;
+      else w_c = w;
+      wave_accepted += (unsigned int)__popcll(__ballot(accept));
+    }
+    bad_width |= !(w > R(0));
+    a.energy[c] = e;
+    a.width[(long long)wrow * n + c] = w;
+  }
+  if ((threadIdx.x & 63) == 0 && wave_accepted) {
+    unsigned long long *slot = a.accept_slots + (size_t)blockIdx.x * (kStepThreads >> 6) + (threadIdx.x >> 6);
+    *slot += (unsigned long long)wave_accepted;
+  }
+  const unsigned int bits = (bad_energy ? ST_NONFINITE_ENERGY : 0u) | (bad_width ? ST_BAD_WIDTH : 0u);
+  if (bits) atomicOr(a.status, bits);
+}
+
+template <typename R>
+__global__ void __launch_bounds__(kBlockThreads) k_init_energy_runtime_dense(const R *x, R *energy, long long n, unsigned int *status,
+                                                                              int D, const R *__restrict__ folded) {
+  const long long stride = (long long)gridDim.x * kBlockThreads;
+  for (long long c = (long long)blockIdx.x * kBlockThreads + threadIdx.x; c < n; c += stride) {
+    R e = R(0);
+    const R *trow = folded;
+    for (int i = 0; i < D; ++i) {
+      R y = R(0);
+      for (int j = 0; j <= i; ++j) y += trow[j] * x[(long long)j * n + c];
+      e += x[(long long)i * n + c] * y;
+      trow += i + 1;
+    }
+    energy[c] = e;
+    if (!Num<R>::finite(e)) atomicOr(status, (unsigned int)ST_NONFINITE_ENERGY);
+  }
+}
+
+bool has_energy(int kind) { return kind == ME_ENERGY_ISO_QUAD || kind == ME_ENERGY_DIAG_QUAD || kind == ME_ENERGY_DENSE_QUAD; }
 int energy_terms(int kind) { return has_energy(kind) ? 1 : 0; }
 
 template <typename R>
@@ -197,6 +336,10 @@ bool fill(RuntimeStep<R> &p, int nr, int nc, int group, int kind, const double *
     p.weights = (const R *)coef_device;        // expanded to D entries by me_create (me_api.hip)
     return true;
   }
+  if (kind == ME_ENERGY_DENSE_QUAD) {
+    const int d = nr + 2 * nc;
+    return n_coef == d * d && coef_device != nullptr;    // coef_device = the FOLDED triangle, made by me_create
+  }
   return false;
 }
 
@@ -209,7 +352,7 @@ int grid_of(long long n, int requested) {
 template <typename R>
 hipError_t step(const StepLaunch &l, hipStream_t stream) {
   if (l.inj_normals) return hipErrorNotSupported;
-  if (l.cov_kind != CK_IDENTITY) return hipErrorNotSupported;
+  if (l.cov_kind != CK_IDENTITY && !(l.cov_kind == CK_SHARED && l.n_complex == 0)) return hipErrorNotSupported;
   const bool mixed = l.n_real > 0 && l.n_complex > 0;
   if (l.group != GROUP_ALL && !mixed) return hipErrorInvalidValue;
   RuntimeStep<R> p;
@@ -237,6 +380,27 @@ hipError_t step(const StepLaunch &l, hipStream_t stream) {
   a.damping = (R)l.damping;
   a.up = (R)(l.ratio * (1.0 - l.target_acceptance) / l.damping);
   a.down = (R)(-l.ratio * l.target_acceptance / l.damping);
+  if (l.energy_kind == ME_ENERGY_DENSE_QUAD || l.cov_kind == CK_SHARED) {
+    // the LDS form: one wavefront per block, x' (and g) parked per lane
+    const bool shared = l.cov_kind == CK_SHARED;
+    const size_t lds = (size_t)(l.n_real + 2 * l.n_complex) * kStepThreads * sizeof(R) * (shared ? 2 : 1);
+    if (lds > kRuntimeLdsLimit) return hipErrorNotSupported;
+    a.factor = (const R *)l.factor;
+    long long blocks = (l.n + kStepThreads - 1) / kStepThreads;
+    if (l.grid_blocks > 0 && blocks > l.grid_blocks) blocks = l.grid_blocks;
+    static PerDevice<hipError_t> attr_cache[2];
+    int device = 0;
+    if (hipError_t rc = hipGetDevice(&device); rc != hipSuccess) return rc;
+    const hipError_t rc = attr_cache[shared ? 1 : 0].get(device, [shared] {
+      return shared ? hipFuncSetAttribute((const void *)k_step_runtime_lds<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRuntimeLdsLimit)
+                    : hipFuncSetAttribute((const void *)k_step_runtime_lds<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRuntimeLdsLimit);
+    });
+    if (rc != hipSuccess) return rc;
+    const R *folded = l.energy_kind == ME_ENERGY_DENSE_QUAD ? (const R *)l.coef_device : nullptr;
+    if (shared) hipLaunchKernelGGL((k_step_runtime_lds<R, true>), dim3((unsigned)blocks), dim3(kStepThreads), lds, stream, a, p, folded);
+    else hipLaunchKernelGGL((k_step_runtime_lds<R, false>), dim3((unsigned)blocks), dim3(kStepThreads), lds, stream, a, p, folded);
+    return hipGetLastError();
+  }
   // the acceptance slots are sized for 64-thread blocks over all chains; a 256-thread grid uses a quarter of them
   hipLaunchKernelGGL(k_step_runtime<R>, dim3(grid_of(l.n, l.grid_blocks)), dim3(kBlockThreads), 0, stream, a, p);
   return hipGetLastError();
@@ -261,6 +425,11 @@ template <typename R>
 hipError_t init_energy(const EnergyLaunch &l, hipStream_t stream) {
   RuntimeStep<R> p;
   if (!fill(p, l.n_real, l.n_complex, GROUP_ALL, l.energy_kind, l.coef_host, l.n_coef, l.coef_device)) return hipErrorInvalidValue;
+  if (l.energy_kind == ME_ENERGY_DENSE_QUAD) {
+    hipLaunchKernelGGL(k_init_energy_runtime_dense<R>, dim3(grid_of(l.n, l.grid_blocks)), dim3(kBlockThreads), 0, stream,
+                       (const R *)l.x, (R *)l.energy, l.n, l.status, l.n_real + 2 * l.n_complex, (const R *)l.coef_device);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_init_energy_runtime<R>, dim3(grid_of(l.n, l.grid_blocks)), dim3(kBlockThreads), 0, stream,
                      (const R *)l.x, (R *)l.energy, l.n, l.status, p);
   return hipGetLastError();

@@ -164,7 +164,8 @@ def test_runtime_dimension_kernel_set_is_the_fallback_beyond_96_dof():
     lib = _capi.load()
     assert lib.me_supported(_capi.ME_F32, 200, 0, _capi.ENERGY_ISO_QUAD) == 1
     assert lib.me_supported(_capi.ME_F64, 60, 25, _capi.ENERGY_DIAG_QUAD) == 1
-    assert lib.me_supported(_capi.ME_F32, 200, 0, _capi.ENERGY_DENSE_QUAD) == 0
+    assert lib.me_supported(_capi.ME_F32, 200, 0, _capi.ENERGY_DENSE_QUAD) == 1       # LDS-resident form
+    assert lib.me_supported(_capi.ME_F32, 200, 0, _capi.ENERGY_LANDAU_TOY) == 0
     assert lib.me_supported(_capi.ME_F32, 5, 0, _capi.ENERGY_ISO_QUAD) == 0          # small sizes are built on demand instead
     cfg = _capi.MeConfig()
     init, coef = np.zeros(200), np.ones(1)
@@ -179,3 +180,13 @@ def test_runtime_dimension_kernel_set_is_the_fallback_beyond_96_dof():
     assert "identity proposal shape" in _capi.last_error()
     cfg.cov_mode = _capi.COV_FIXED
     assert lib.me_create(ctypes.byref(cfg), ctypes.byref(handle)) == _capi.ME_ERR_HIP     # accepted; no GPU here
+    cfg.cov_mode = _capi.COV_POOLED
+    assert lib.me_create(ctypes.byref(cfg), ctypes.byref(handle)) == _capi.ME_ERR_HIP     # one shared factor: pure real spaces
+    # a dense quadratic form is staged in LDS: 1 000 parameters do not fit
+    big = np.zeros(1000)
+    dense = np.zeros(1000 * 1000)
+    cfg.n_real, cfg.energy_kind, cfg.n_energy_coeffs, cfg.cov_mode = 1000, _capi.ENERGY_DENSE_QUAD, dense.size, _capi.COV_FIXED
+    cfg.energy_coeffs = dense.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    cfg.initial_params = big.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    assert lib.me_create(ctypes.byref(cfg), ctypes.byref(handle)) == _capi.ME_ERR_UNSUPPORTED
+    assert "LDS" in _capi.last_error()

@@ -98,12 +98,48 @@ def test_f32_200_real_stationary_variances():
     assert np.allclose(eng.energy_total, (a * x * x).sum(axis=1), rtol=2e-4)   # the ledger is the energy of the state
 
 
+@pytest.mark.parametrize("shape", ["identity", "shared"])
+def test_dense_energy_and_shared_factor_at_120_real(shape):
+    """Beyond 96 degrees of freedom a dense quadratic form (x' parked in LDS, folded triangle through wave-uniform loads)
+    and one shared proposal factor (cov_mode="pooled", pure real spaces) follow the oracle: an asymmetric A (only its
+    symmetric part may matter), fused and one-sweep launches, the wall."""
+    nr, n, seed = 120, 100, 35
+    rng = np.random.default_rng(8)
+    m = rng.standard_normal((nr, nr))
+    amat = m @ m.T / nr + np.identity(nr) + 0.05 * np.triu(rng.standard_normal((nr, nr)), 1)
+    x0 = [0.5] + list(np.linspace(-0.1, 0.1, nr - 1))
+    kw = dict(temp=1.0, n_chains=n, seed=seed, dtype="f64", sampling_width=0.05)
+    okw = dict(seed=seed, temp=1.0, initial_real_params=x0, sampling_width=0.05, adapt_shape=False,
+               reject=lambda p: np.abs(p[:, 0]) >= 1.0)
+    if shape == "shared":
+        b = rng.standard_normal((nr, nr))
+        cov = 0.5 * np.linalg.inv(0.5 * (amat + amat.T)) + 0.02 * (b @ b.T) / nr
+        eng = me.MetropolisEngine(me.DenseQuadratic(amat), me.AbsReal0AtLeast(1.0), x0, None, cov_mode="pooled", **kw)
+        eng.set_shared_factor(np.linalg.cholesky(cov)[np.tril_indices(nr)])
+        ora = ManyChainOracle(nr, 0, energies.dense_quadratic(nr, 0, amat), n, covariance_matrix_real=cov, **okw)
+    else:
+        eng = me.MetropolisEngine(me.DenseQuadratic(amat), me.AbsReal0AtLeast(1.0), x0, None, cov_mode="fixed", **kw)
+        ora = ManyChainOracle(nr, 0, energies.dense_quadratic(nr, 0, amat), n, **okw)
+    assert np.allclose(eng.energy_total, ora.energy, rtol=1e-12)
+    for k in range(16):
+        sweeps = 1 if k % 2 else 3
+        eng.step_all(sweeps)
+        ora.step(sweeps)
+        eng.measure()
+        ora.measure()
+    _compare(eng, ora, nr, 0)
+    assert 0.05 < ora.accepted / ora.proposed < 0.95
+    assert np.all(np.abs(eng._get(0)[:, 0]) < 1.0)
+
+
 def test_unsupported_combinations_fail_loudly():
     with pytest.raises(NotImplementedError, match="identity proposal shape"):
         me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 120, None, temp=1.0, n_chains=8)      # cov_mode="reference"
+    with pytest.raises(NotImplementedError, match="LDS"):
+        me.MetropolisEngine(me.DenseQuadratic(np.identity(700)), None, [0.0] * 700, None, temp=1.0, n_chains=8,
+                            cov_mode="fixed")                                                  # x' would not fit in LDS
     with pytest.raises(NotImplementedError):
-        me.MetropolisEngine(me.DenseQuadratic(np.identity(120)), None, [0.0] * 120, None, temp=1.0, n_chains=8,
-                            cov_mode="fixed")
+        me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 100, [0j] * 10, temp=1.0, n_chains=8, cov_mode="pooled")
     eng = me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 120, None, temp=1.0, n_chains=8, cov_mode="fixed")
     with pytest.raises(NotImplementedError):
         eng.covariance_matrix_real
