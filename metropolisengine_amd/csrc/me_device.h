@@ -10,6 +10,7 @@
 #pragma once
 
 #include <type_traits>
+#include <utility>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -476,12 +477,19 @@ __host__ __device__ constexpr int cre(int pr, int i, int j) { return pr + i * i 
 __host__ __device__ constexpr int cim(int pr, int i, int j) { return pr + i * i + 2 * j + 1; }
 __host__ __device__ constexpr int cdiag(int pr, int i) { return pr + i * i + 2 * i; }
 
-// LDS home of the normals of a sweep for the streamed-factor proposal (k_step, STREAM_FACTOR)
-template <typename R, int NR>
-__device__ __forceinline__ R (*stream_normals())[kStepThreads] {
-  __shared__ R g[NR][kStepThreads];
-  return g;
+// fn(integral_constant<int, 0>) ... fn(integral_constant<int, N - 1>): a loop whose index is a constant expression
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&fn, std::integer_sequence<int, I...>) {
+  (fn(std::integral_constant<int, I>{}), ...);
 }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&fn) {
+  static_for_impl(fn, std::make_integer_sequence<int, N>{});
+}
+// bytes of one chunk of the streamed factor per lane (two chunks live in registers)
+#ifndef ME_STREAM_CHUNK_BYTES
+#define ME_STREAM_CHUNK_BYTES 128
+#endif
 
 // INJECT = true replaces the Philox draws by caller-provided streams (test hook: replays the reference's golden
 // trajectories, tests/golden/, through the very same proposal / accept / adapt code).
@@ -527,8 +535,7 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   const bool stale_total = MIXED && GROUP == GROUP_ALL && a.stale_total != 0;
   constexpr bool PER_CHAIN = CK == CK_PER_CHAIN || CK == CK_PER_CHAIN_NT;
   constexpr int PF = PER_CHAIN ? NR * (NR + 1) / 2 + NC * NC : 0;
-  // per-chain factors beyond the register-resident size are streamed (pure real spaces only; launched with
-  // kStepThreads-wide blocks: the parked normals are sized for them)
+  // per-chain factors beyond the register-resident size are streamed (pure real spaces only)
   constexpr bool STREAM_FACTOR = PER_CHAIN && PF > kMaxPackedInRegisters;
   static_assert(!STREAM_FACTOR || NC == 0, "streamed per-chain factors exist for pure real parameter spaces");
   const TiledField<R> ffac(a.factor, a.n, STREAM_FACTOR ? 0 : PF);
@@ -610,34 +617,53 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
         }
       } else if constexpr (STREAM_FACTOR) {
         // Packed factors too large for registers (more than 160 entries; pure real spaces, e.g. 64 parameters = 2 080
-        // entries = 8-16 KB per chain and step): the normals are parked in LDS so that the row products can be ROLLED
-        // loops, and each row of L streams through the lane in batches of 16 loads issued ahead of their multiply-adds (32 per
-        // batch made hipcc trade registers for scratch).
-        // The field may pass the 4 GiB a buffer descriptor spans: a 64-bit pointer walks the chain's tile instead.
-        // (the clobber keeps the 2 080 loop-invariant loads inside the sweep loop: hoisted, they went to 16 KB of scratch)
+        // entries = 8-16 KB per chain and step).  The chain's entries are one run of its tile (64 values apart), read
+        // exactly once per step -- the kernel is a STREAM and lives on bytes in flight: with one wavefront per SIMD a
+        // batch of loads that is waited for before the next is issued exposes the full memory latency 130 times per
+        // step (the first version: 2.9 ms at 2^19 chains against a traffic floor of 0.8).  So: straight-line code over
+        // the whole triangle in chunks of ME_STREAM_CHUNK entries, chunk c+1 is in flight while chunk c is multiplied,
+        // normals and proposals in registers with compile-time indices.
+        // The field may pass the 4 GiB a buffer descriptor spans: the descriptor covers the wavefront's own tile.
+        // (the clobber keeps the loop-invariant loads inside the sweep loop: hoisted, they went to 16 KB of scratch)
         asm volatile("" ::: "memory");
-        R(*gs)[kStepThreads] = stream_normals<R, NR>();
+        constexpr int CH = (int)(ME_STREAM_CHUNK_BYTES / sizeof(R));
+        const R *tile_base = a.factor + (c >> 6) * (long long)PF * 64;
+        const unsigned long long tb = (unsigned long long)tile_base;
+        // (readfirstlane returns int: through unsigned, or a low half with bit 31 set sign-extends into the high half)
+        const R *tile_uniform = (const R *)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(tb >> 32)) << 32) |
+                                            (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)tb));
+        const __amdgpu_buffer_rsrc_t tile = __builtin_amdgcn_make_buffer_rsrc(const_cast<R *>(tile_uniform), 0,
+                                                                               (unsigned int)(PF * 64 * sizeof(R)), 0x00020000);
+        const unsigned int lane_off = (unsigned int)(c & 63) * (unsigned int)sizeof(R);
+        auto entry = [&](int k) -> R {
+          constexpr int AUX = CK == CK_PER_CHAIN_NT ? ME_NT_AUX : 0;
+          if constexpr (sizeof(R) == 4)
+            return __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b32(tile, lane_off, (unsigned int)k * 64u * 4u, AUX));
+          else
+            return __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b64(tile, lane_off, (unsigned int)k * 64u * 8u, AUX));
+        };
+        R f[2][CH];
 #pragma unroll
-        for (int j = 0; j < NR; ++j) gs[j][threadIdx.x] = g[j];
-        const R *row = a.factor + (c >> 6) * (long long)PF * 64 + (c & 63);      // tile-major: entries 64 values apart
-        asm volatile("" : "+v"(row));     // opaque per sweep: otherwise 200 derived row addresses are hoisted and spilled
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
+        for (int u = 0; u < CH; ++u)
+          if (u < PF) f[0][u] = entry(u);
+        // (row and column are template constants: as `#pragma unroll` loop variables a row of 64 columns with its chunk of
+        // loads passes LLVM's size limit for forced unrolling, is unrolled too late, and the arrays stay in scratch)
+        static_for<NR>([&](auto row_index) {
+          constexpr int i = decltype(row_index)::value;
           R acc = 0;
-          int j = 0;
-#pragma unroll 1
-          for (; j + 16 <= i + 1; j += 16) {
-            R f[16];
+          static_for<i + 1>([&](auto col_index) {
+            constexpr int j = decltype(col_index)::value, k = tri(i, j);
+            if constexpr (k % CH == 0) {   // entering a chunk: put the one after it in flight first
+              __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 16; ++u) f[u] = CK == CK_PER_CHAIN_NT ? __builtin_nontemporal_load(row + (j + u) * 64) : row[(j + u) * 64];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) acc += f[u] * gs[j + u][threadIdx.x];
-          }
-#pragma unroll 1
-          for (; j <= i; ++j) acc += (CK == CK_PER_CHAIN_NT ? __builtin_nontemporal_load(row + j * 64) : row[j * 64]) * gs[j][threadIdx.x];
+              for (int u = 0; u < CH; ++u)
+                if (k + CH + u < PF) f[(k / CH + 1) & 1][u] = entry(k + CH + u);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            acc = j == 0 ? f[(k / CH) & 1][k % CH] * g[0] : acc + f[(k / CH) & 1][k % CH] * g[j];
+          });
           xp[i] = x[i] + w_r * acc;
-          row += (i + 1) * 64;
-        }
+        });
       } else {
         if constexpr (MOVE_REAL) {
 #pragma unroll
