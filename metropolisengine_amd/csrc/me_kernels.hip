@@ -10,6 +10,8 @@
 #include "me_dense_mfma.h"
 #include "me_dense_bf16x3.h"
 #include "me_dense_f64.h"
+#include "me_factor_tile.h"
+#include "me_per_device.h"
 #include "me_pool_gram.h"
 #include "me_magphase.h"
 
@@ -403,8 +405,14 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
 #elif ME_PER_CHAIN == 2
   static_assert(NC == 0 && P > kMaxPackedInRegisters, "ME_PER_CHAIN=2 is for pure real spaces with more than 160 packed entries");
   if (l.cov && l.update_cov && l.write_factor) {
-    if (nt) hipLaunchKernelGGL((k_factor_stream<R, NR, true>), grid, block, 0, stream, (const R *)l.cov, (R *)l.factor, l.status, l.n);
-    else hipLaunchKernelGGL((k_factor_stream<R, NR, false>), grid, block, 0, stream, (const R *)l.cov, (R *)l.factor, l.status, l.n);
+    if constexpr (NR <= 64) {     // a lane group per chain, a lane per row: every matrix read once (me_factor_tile.h)
+      const hipError_t err = nt ? launch_factor_tile<R, NR, true>((const R *)l.cov, (R *)l.factor, l.status, l.n, stream)
+                                : launch_factor_tile<R, NR, false>((const R *)l.cov, (R *)l.factor, l.status, l.n, stream);
+      if (err != hipSuccess) return err;
+    } else {                      // one lane per chain, finished rows re-read from global memory
+      if (nt) hipLaunchKernelGGL((k_factor_stream<R, NR, true>), grid, block, 0, stream, (const R *)l.cov, (R *)l.factor, l.status, l.n);
+      else hipLaunchKernelGGL((k_factor_stream<R, NR, false>), grid, block, 0, stream, (const R *)l.cov, (R *)l.factor, l.status, l.n);
+    }
   }
 #endif
   return hipGetLastError();
