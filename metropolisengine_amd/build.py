@@ -192,10 +192,11 @@ def build_examples(force=False):
     src = os.path.join(REPO_DIR, "examples", "user_energy_cylinder.h")
     terms = os.path.join(REPO_DIR, "examples", "user_energy_landau_terms.h")
     build(verbose=False)
-    with concurrent.futures.ThreadPoolExecutor(max_workers=5) as pool:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=6) as pool:
         jobs = [pool.submit(build_user_energy, src, "cylinder", 2, 7, force), pool.submit(build_dims, 3, 2, force),
                 pool.submit(build_user_energy, terms, "landau_terms", 2, 1, force),
                 pool.submit(build_dims, 1, 13, force),     # 170 packed entries: the streaming-covariance path
+                pool.submit(build_dims, 24, 0, force),     # streamed per-chain shapes with two chains per wavefront
                 pool.submit(build_dims, 96, 0, force)]     # the largest register-resident parameter space
         return [job.result() for job in jobs]
 

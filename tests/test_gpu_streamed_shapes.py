@@ -54,6 +54,34 @@ def test_64_real_per_chain_shapes_follow_the_oracle(kind):
     assert np.allclose(eng.covariance_matrix_real, ora.cov_real, rtol=0, atol=1e-8)
 
 
+@pytest.mark.parametrize("nr", [24, 96])
+def test_other_streamed_sizes_follow_the_oracle(nr):
+    """The streamed kernels at the sizes either side of 64: 24 parameters (300 packed entries; k_factor_tile with TWO chains
+    per wavefront, pivots by ds_bpermute) and 96 (4 656 entries; beyond a lane per row, so k_factor_stream), both compiled
+    on demand (build.build_dims), float64 against the many-chain oracle."""
+    n, seed = 75, 47
+    x0 = list(np.linspace(-0.2, 0.2, nr))
+    weights = tuple(np.linspace(0.5, 2.0, nr))
+    eng = me.MetropolisEngine(me.DiagQuadratic(weights), None, x0, None, temp=1.0, n_chains=n, seed=seed, dtype="f64",
+                              sampling_width=0.1, cov_mode="reference")
+    ora = ManyChainOracle(nr, 0, energies.diag_quadratic(nr, 0, weights, ()), n, seed=seed, temp=1.0,
+                          initial_real_params=x0, sampling_width=0.1)
+    for k in range(54):
+        eng.step_all(2)
+        ora.step(2)
+        eng.measure()
+        ora.measure()
+    fr, _ = eng.proposal_factors()
+    assert np.allclose(eng.covariance_matrix_real, ora.cov_real, rtol=0, atol=1e-9)
+    assert np.allclose(fr, ora.factor_real, rtol=0, atol=1e-8)
+    for sweeps in (1, 3):
+        eng.step_all(sweeps)
+        ora.step(sweeps)
+    assert np.allclose(eng._get(0), ora.x, rtol=0, atol=1e-8)
+    assert np.allclose(eng.energy_total, ora.energy, rtol=0, atol=1e-8)
+    assert eng.accept_stats() == (ora.accepted, ora.proposed)
+
+
 def test_64_real_per_chain_shapes_float32_shards_and_state():
     """float32: a sub-range of a larger engine is bitwise the small engine that owns the same chain ids (covariance and
     factor included), the factors reproduce their covariance, and a checkpoint resumes bit for bit."""
