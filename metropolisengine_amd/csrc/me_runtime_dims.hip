@@ -13,10 +13,11 @@
 //   k_measure_runtime, k_init_energy_runtime: the same loops over d for the running means / observables / energy.
 //
 //   k_step_runtime_lds  what cannot stream: a DENSE quadratic form needs all of x' at once, a SHARED proposal factor all of
-//                    g.  Both are parked in LDS ([D][64 lanes], one wavefront per block), the folded triangle of A
-//                    (T_ij = A_ij + A_ji) and the packed factor L are read through wave-uniform (scalar) loads, and the
-//                    two O(D^2) products are rolled loops.  Limits: the LDS a block may use (D <= ~290 in float64 with
-//                    the identity shape, ~145 with a shared factor; twice that in float32).
+//                    g.  Both are parked in LDS ([D][64 lanes], one wavefront per block); the two O(D^2) triangle
+//                    products are register-blocked 16 x 16 with the tiles of T (folded triangle of A, T_ij = A_ij + A_ji,
+//                    or the packed factor L) loaded coalesced and handed around by v_readlane (tri_rows_blocked).
+//                    Limits: the LDS a block may use (D <= ~290 in float64 with the identity shape, ~145 with a shared
+//                    factor; twice that in float32).
 //
 // Supported: ME_ENERGY_ISO_QUAD, ME_ENERGY_DIAG_QUAD (streamed), ME_ENERGY_DENSE_QUAD (LDS); the identity proposal
 // shape (ME_COV_FIXED) and, for pure real spaces, one shared factor (ME_COV_POOLED); the built-in wall, step_all and
@@ -189,6 +190,70 @@ __global__ void __launch_bounds__(kBlockThreads) k_init_energy_runtime(const R *
 // Everything that needs the whole proposal (dense energy) or all normals (shared factor): see the header comment.
 // `folded`: D(D+1)/2 values T_ij (i >= j) for ME_ENERGY_DENSE_QUAD; `factor`: the packed shared factor (pure real
 // spaces: the lower triangle of L, row-major) for CK_SHARED.  Dynamic LDS: xp[D][64] (+ g[D][64] with a factor).
+// value of lane `src` (a compile-time constant after unrolling) as a wave-uniform scalar
+template <typename R>
+__device__ __forceinline__ R from_lane(R v, int src) {
+  if constexpr (sizeof(R) == 4) {
+    return __builtin_bit_cast(R, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+  } else {
+    const unsigned long long w = __builtin_bit_cast(unsigned long long, v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)w, src);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(w >> 32), src);
+    return __builtin_bit_cast(R, ((unsigned long long)hi << 32) | lo);
+  }
+}
+
+// y_i = sum_{j <= i} T_ij v_j for a packed row-major lower triangle T in global memory (the same for every chain) and a
+// vector v parked in LDS ([D][64], one column per lane), handed row by row to done(i, y_i, v_i).  Register-blocked
+// 16 x 16: sixteen v_j are read from LDS once per block and serve sixteen rows.  A 16 x 16 tile of T is ONE coalesced
+// vector load -- lane l holds T[i0 + l/4][j0 + 4 (l%4) .. +3] -- issued a block ahead of its use, and T_ij reaches the
+// multiply-add as a scalar operand through v_readlane.  History (128 parameters x 2^17 chains, dense energy, float32 /
+// float64 per sweep): one LDS read + one scalar load per multiply-add 816 / 2 049 us; 16 x 16 blocks with a row's T_ij
+// as one contiguous scalar load 355 / 770 us (scalar-load latency exposed: ~100 SGPRs hold five rows in flight, one
+// wavefront per SIMD has nothing else to run); tiles through vector loads + v_readlane: see DESIGN.md section 4.
+template <typename R, class RowDone>
+__device__ __forceinline__ void tri_rows_blocked(const R *__restrict__ tri_packed, R (*v)[kStepThreads], int D, int lane, RowDone &&done) {
+  constexpr int B = 16;
+  const int tr = lane >> 2, tc = (lane & 3) * 4;      // this lane's row and first column inside a tile
+  // tile (i0, j0): full (every column exists in every row) left of the diagonal, triangular on it
+  auto load_tile = [&](int i0, int j0, bool diagonal, R (&t)[4]) {
+    int i = i0 + tr;
+    if (i >= D) i = D - 1;                             // ragged last block: a valid address, values unused
+    const R *src = tri_packed + (size_t)i * (size_t)(i + 1) / 2 + j0 + tc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = (!diagonal || j0 + tc + q <= i) ? src[q] : R(0);
+  };
+  for (int i0 = 0; i0 < D; i0 += B) {
+    R acc[B];
+#pragma unroll
+    for (int r = 0; r < B; ++r) acc[r] = R(0);
+    R t[4];
+    load_tile(i0, 0, i0 == 0, t);
+    for (int j0 = 0; j0 < i0; j0 += B) {               // full blocks left of the diagonal
+      R tn[4];
+      load_tile(i0, j0 + B, j0 + B == i0, tn);         // the next tile of this block row (the last one: the diagonal tile)
+      R vj[B];
+#pragma unroll
+      for (int u = 0; u < B; ++u) vj[u] = v[j0 + u][lane];
+#pragma unroll
+      for (int r = 0; r < B; ++r)
+#pragma unroll
+        for (int u = 0; u < B; ++u) acc[r] += from_lane(t[u & 3], r * 4 + (u >> 2)) * vj[u];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t[q] = tn[q];
+    }
+    R vd[B];                                           // the diagonal tile: row i0 + r has r + 1 entries (the rest loaded as 0)
+#pragma unroll
+    for (int u = 0; u < B; ++u) vd[u] = i0 + u < D ? v[i0 + u][lane] : R(0);
+#pragma unroll
+    for (int r = 0; r < B; ++r) {
+#pragma unroll
+      for (int u = 0; u <= r; ++u) acc[r] += from_lane(t[u & 3], r * 4 + (u >> 2)) * vd[u];
+      if (i0 + r < D) done(i0 + r, acc[r], vd[r]);
+    }
+  }
+}
+
 template <typename R, bool SHARED>
 __global__ void __launch_bounds__(kStepThreads) k_step_runtime_lds(StepArgs<R> a, RuntimeStep<R> p, const R *__restrict__ folded) {
   using N_ = Num<R>;
@@ -204,7 +269,11 @@ __global__ void __launch_bounds__(kStepThreads) k_step_runtime_lds(StepArgs<R> a
   bool bad_energy = false, bad_width = false;
   const long long stride = (long long)gridDim.x * kStepThreads, n = a.n;
   const int lane = threadIdx.x;
-  for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < n; c += stride) {
+  // every lane of a wavefront stays in the loop (the triangle products hand T around with v_readlane: a tile entry may
+  // sit in any lane): lanes past the last chain shadow chain n - 1 and write nothing
+  for (long long c0 = (long long)blockIdx.x * kStepThreads; c0 < n; c0 += stride) {
+    const bool valid = c0 + lane < n;
+    const long long c = valid ? c0 + lane : n - 1;
     R *xc = a.x + c;
     R e = a.energy[c];
     const int wrow = mixed ? p.group : 0;
@@ -226,6 +295,16 @@ __global__ void __launch_bounds__(kStepThreads) k_step_runtime_lds(StepArgs<R> a
         return philox4x32_10(ctr, a.seed_lo, a.seed_hi);
       };
       const R s_r = w_r, s_c = w_c * R(0.70710678118654752440);
+      // ---- the state into x' first, sixteen loads in flight at a time (issued one by one where they are used, every
+      // load would expose the whole memory latency: one wavefront per SIMD has nothing else to run)
+      for (int d0b = 0; d0b < D; d0b += 16) {
+        R xd[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) xd[t] = d0b + t < D ? xc[(long long)(d0b + t) * n] : R(0);
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          if (d0b + t < D) xp[d0b + t][lane] = xd[t];
+      }
       // ---- the normals: straight into x' (identity shape) or parked (shared factor)
       for (int b = 0; 4 * b < NW; ++b) {
         const U4 o = block_of(b);
@@ -237,33 +316,18 @@ __global__ void __launch_bounds__(kStepThreads) k_step_runtime_lds(StepArgs<R> a
           const int d = 4 * b + t;
           if (d < D) {
             if constexpr (SHARED) gs[d][lane] = g[t];
-            else {
-              const R xd = xc[(long long)d * n];
-              xp[d][lane] = (d >= d0 && d < d1) ? fma_(d < nr ? s_r : s_c, g[t], xd) : xd;
-            }
+            else if (d >= d0 && d < d1) xp[d][lane] = fma_(d < nr ? s_r : s_c, g[t], xp[d][lane]);
           }
         }
       }
       if constexpr (SHARED) {
-        // x' = x + w L g, row by row; L packed lower triangle, wave-uniform reads (pure real spaces: nc == 0)
-        const R *lrow = a.factor;
-        for (int i = 0; i < D; ++i) {
-          R acc = R(0);
-          for (int j = 0; j <= i; ++j) acc += lrow[j] * gs[j][lane];
-          xp[i][lane] = fma_(s_r, acc, xc[(long long)i * n]);
-          lrow += i + 1;
-        }
+        // x' = x + w L g, row by row; L packed lower triangle (pure real spaces: nc == 0)
+        tri_rows_blocked(a.factor, gs, D, lane, [&](int i, R acc, R) { xp[i][lane] = fma_(s_r, acc, xp[i][lane]); });
       }
       // ---- energy of the proposal
       R e_new = R(0);
       if (p.energy_kind == ME_ENERGY_DENSE_QUAD) {
-        const R *trow = folded;
-        for (int i = 0; i < D; ++i) {
-          R y = R(0);
-          for (int j = 0; j <= i; ++j) y += trow[j] * xp[j][lane];
-          e_new += xp[i][lane] * y;
-          trow += i + 1;
-        }
+        tri_rows_blocked(folded, xp, D, lane, [&](int, R y, R xi) { e_new += xi * y; });
       } else {
         for (int d = 0; d < D; ++d) e_new += weight_of(p, d) * xp[d][lane] * xp[d][lane];
       }
@@ -274,8 +338,8 @@ __global__ void __launch_bounds__(kStepThreads) k_step_runtime_lds(StepArgs<R> a
       const R diff = e_new - e;
       bool accept = diff <= R(0);
       if (a.temp > R(0)) accept = accept || N_::uphill(u, diff, a.inv_temp, a.inv_temp_log2e);
-      accept = accept && !rejected;
-      bad_energy |= (!rejected && !N_::finite(e_new));
+      accept = accept && !rejected && valid;
+      bad_energy |= (valid && !rejected && !N_::finite(e_new));
       if (accept)
         for (int d = d0; d < d1; ++d) xc[(long long)d * n] = xp[d][lane];
       e = accept ? e_new : e;
@@ -285,9 +349,11 @@ __global__ void __launch_bounds__(kStepThreads) k_step_runtime_lds(StepArgs<R> a
       else w_c = w;
       wave_accepted += (unsigned int)__popcll(__ballot(accept));
     }
-    bad_width |= !(w > R(0));
-    a.energy[c] = e;
-    a.width[(long long)wrow * n + c] = w;
+    bad_width |= valid && !(w > R(0));
+    if (valid) {
+      a.energy[c] = e;
+      a.width[(long long)wrow * n + c] = w;
+    }
   }
   if ((threadIdx.x & 63) == 0 && wave_accepted) {
     unsigned long long *slot = a.accept_slots + (size_t)blockIdx.x * (kStepThreads >> 6) + (threadIdx.x >> 6);
