@@ -30,8 +30,9 @@
 // Measured (MI355X, 2^19 chains x 64 parameters, tools/dev/time_factor_tile.py; -DME_FACTOR_TILE_SKIP_FACTOR / _SKIP_COPY
 // time the phases apart): float64 13 ms = 4.8 ms copy (17 GB, 3.6 TB/s) + 8 ms factor; float32 8.4 = 3.0 + 5.4.  The
 // factor phase is LDS-bandwidth bound: a broadcast read still moves 64 lanes x 8 bytes, 2 016 of them per matrix are
-// 2 MB of LDS traffic per chain, 6.8 ms at 128 bytes per clock and CU.  Next step there: two rows per lane and two
-// chains per wavefront halve the broadcasts per chain (512 registers per lane in float64).
+// 2 MB of LDS traffic per chain, 6.8 ms at 128 bytes per clock and CU.  Two rows per lane and two chains per wavefront
+// halve the broadcasts per matrix: float32 measure() 10.4 -> 7.8 ms; float64 would need 2 x 128 registers for the rows
+// alone and loses more to occupancy than it gains (16.3 -> 19.8 ms), so it keeps one row per lane.
 // History: LDS row-major with the pivot through LDS and IEEE sqrt + division 17 ms (float64); column-major, readlane
 // pivot, sqrt_and_inverse 10 ms; XCD-aware order: -15 % where a run is half a sector (32 bytes).
 #pragma once
@@ -47,12 +48,25 @@ namespace me {
 #ifndef ME_FACTOR_TILE_RUN_BYTES_F64
 #define ME_FACTOR_TILE_RUN_BYTES_F64 64
 #endif
+// rows per lane for more than 32 parameters.  Measured at 64 parameters x 2^19 chains, whole measure(): float32 10.4 ms with
+// one row, 7.8 ms with two; float64 16.3 ms with one, 19.8 ms with two (2 x 64 doubles = 256 registers per lane leave one
+// wavefront per SIMD, and the latencies of the column recurrence are no longer hidden)
+#ifndef ME_FACTOR_TILE_ROWS_PER_LANE_F32
+#define ME_FACTOR_TILE_ROWS_PER_LANE_F32 2
+#endif
+#ifndef ME_FACTOR_TILE_ROWS_PER_LANE_F64
+#define ME_FACTOR_TILE_ROWS_PER_LANE_F64 1
+#endif
 
 template <typename R, int NR>
 struct FactorTile {
   static constexpr int P = NR * (NR + 1) / 2;
   static constexpr int PS = P | 1;                                    // odd chain stride in LDS: the transposing copy spreads over the banks
-  static constexpr int LPC = NR <= 16 ? 16 : NR <= 32 ? 32 : 64;      // lanes per chain (a power of two >= NR)
+  // rows per lane: with two, a broadcast of L_jk serves two rows of each of two chains -- half the LDS traffic per matrix --
+  // and the upper row block drops out of the multiply-adds once j passes it (2 512 instead of 4 032 per pair of matrices)
+  static constexpr int RPL = (NR > 32 && (sizeof(R) == 4 ? ME_FACTOR_TILE_ROWS_PER_LANE_F32 : ME_FACTOR_TILE_ROWS_PER_LANE_F64) == 2) ? 2 : 1;
+  static constexpr int kRowsPerGroup = (NR + RPL - 1) / RPL;
+  static constexpr int LPC = kRowsPerGroup <= 16 ? 16 : kRowsPerGroup <= 32 ? 32 : 64;   // lanes per chain (a power of two)
   static constexpr int CPW = 64 / LPC;                                // chains per wavefront
   // chains per workgroup: a run of ME_FACTOR_TILE_RUN_BYTES per entry, as long as the matrices fit in LDS
   static constexpr int kWanted = (sizeof(R) == 4 ? ME_FACTOR_TILE_RUN_BYTES_F32 : ME_FACTOR_TILE_RUN_BYTES_F64) / (int)sizeof(R);
@@ -105,7 +119,7 @@ __global__ void __launch_bounds__((FactorTile<R, NR>::kThreads))
 k_factor_tile(const R *cov, R *factor, unsigned int *status, long long n) {
   using T = FactorTile<R, NR>;
   using N_ = Num<R>;
-  constexpr int P = T::P, PS = T::PS, G = T::kChains, LPC = T::LPC;
+  constexpr int P = T::P, PS = T::PS, G = T::kChains, LPC = T::LPC, RPL = T::RPL;
   constexpr int kGroupsPerTile = 64 / G;
   constexpr int kRowsPerPass = T::kThreads / G;      // entries a copy pass of the workgroup covers
   extern __shared__ unsigned char lds_raw[];
@@ -113,7 +127,7 @@ k_factor_tile(const R *cov, R *factor, unsigned int *status, long long n) {
   const int t = threadIdx.x;
   const int copy_chain = t % G, copy_row = t / G;
   const int lane = t & 63, wave = t >> 6;
-  const int my_row = lane % LPC;                     // the row of its chain this lane works on
+  const int my_row = lane % LPC;                     // the rows of its chain this lane works on: my_row + r LPC, r < RPL
   bool bad_pivot = false;
   auto col = [](int j) { return j * NR - j * (j - 1) / 2; };       // start of column j of a column-packed lower triangle
   // Row-major packed entry k = tri(i, j) (the order of the global field) sits at col(j) + i - j in LDS.  A thread walks
@@ -202,28 +216,53 @@ k_factor_tile(const R *cov, R *factor, unsigned int *status, long long n) {
     const bool valid = tile * 64 + first + my_chain < n;     // the last tile may be ragged: nothing to flag there
 #endif
 #ifndef ME_FACTOR_TILE_SKIP_FACTOR
-    R a[NR];
+    R a[RPL][NR];
 #pragma unroll
-    for (int k = 0; k < NR; ++k) a[k] = (k <= my_row && my_row < NR) ? mine[col(k) + my_row - k] : R(0);
+    for (int r = 0; r < RPL; ++r)
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const int row = my_row + r * LPC;
+        a[r][k] = (k <= row && row < NR) ? mine[col(k) + row - k] : R(0);
+      }
     static_for<NR>([&](auto column) {
       constexpr int j = decltype(column)::value;
-      R s0 = a[j], s1 = R(0);
+      constexpr int r0 = j / LPC;            // row blocks below r0 are finished: rows r LPC .. r LPC + LPC - 1 < j
+      R s0[RPL], s1[RPL];
+#pragma unroll
+      for (int r = r0; r < RPL; ++r) {
+        s0[r] = a[r][j];
+        s1[r] = R(0);
+      }
 #pragma unroll
       for (int k = 0; k + 1 < j; k += 2) {
-        s0 -= a[k] * mine[col(k) + j - k];
-        s1 -= a[k + 1] * mine[col(k + 1) + j - k - 1];
+        const R l0 = mine[col(k) + j - k], l1 = mine[col(k + 1) + j - k - 1];
+#pragma unroll
+        for (int r = r0; r < RPL; ++r) {
+          s0[r] -= a[r][k] * l0;
+          s1[r] -= a[r][k + 1] * l1;
+        }
       }
-      if constexpr (j % 2 == 1) s0 -= a[j - 1] * mine[col(j - 1) + 1];
-      const R s = s0 + s1;
-      R d = lane_value(s, (lane / LPC) * LPC + j, T::CPW == 1);      // the pivot: row j's own sum
+      if constexpr (j % 2 == 1) {
+        const R l0 = mine[col(j - 1) + 1];
+#pragma unroll
+        for (int r = r0; r < RPL; ++r) s0[r] -= a[r][j - 1] * l0;
+      }
+      R s[RPL];
+#pragma unroll
+      for (int r = r0; r < RPL; ++r) s[r] = s0[r] + s1[r];
+      R d = lane_value(s[r0], (lane / LPC) * LPC + j % LPC, T::CPW == 1);      // the pivot: row j's own sum
       if (!(d > R(0))) {
         bad_pivot = bad_pivot || valid;
         d = R(1e-30);
       }
       R dg, inv;
       sqrt_and_inverse(d, dg, inv);
-      a[j] = my_row == j ? dg : s * inv;
-      if (my_row >= j && my_row < NR) mine[col(j) + my_row - j] = a[j];
+#pragma unroll
+      for (int r = r0; r < RPL; ++r) {
+        const int row = my_row + r * LPC;
+        a[r][j] = row == j ? dg : s[r] * inv;
+        if (row >= j && row < NR) mine[col(j) + row - j] = a[r][j];
+      }
       asm volatile("" ::: "memory");     // the column is in LDS (in program order) before row j + 1 is broadcast from there
     });
 #endif
