@@ -429,6 +429,10 @@ constexpr auto pool_stage1_f32() -> hipError_t (*)(const void *, long long, doub
   else if constexpr (D + NR + NC <= 32) return launch_pool_gram32<NR, NC>;
   else return nullptr;
 }
+constexpr auto pool_stage1_f64() -> hipError_t (*)(const void *, long long, double *, int, hipStream_t) {
+  if constexpr (NR == 64 && NC == 0) return launch_pool_gram64_f64;
+  else return nullptr;
+}
 #if ME_DENSE && !defined(ME_USER_SOURCE)
 hipError_t prepare_matrix_f32(const void *factor_full, void *image, hipStream_t stream) {
   if constexpr (NR == 64 && NC == 0) {
@@ -448,10 +452,10 @@ hipError_t prepare_matrix_f64(const void *matrix, void *image, hipStream_t strea
   return hipSuccess;
 }
 constexpr size_t kMatrixImageBytesF64 = (NR == 64 && NC == 0) ? sizeof(double) * kDense64F64ImageDoubles : 0;
-#define ME_PREPARE_MATRIX_F64 kMatrixImageBytesF64, (kMatrixImageBytesF64 ? prepare_matrix_f64 : nullptr), nullptr
+#define ME_PREPARE_MATRIX_F64 kMatrixImageBytesF64, (kMatrixImageBytesF64 ? prepare_matrix_f64 : nullptr), pool_stage1_f64()
 #else
 #define ME_PREPARE_MATRIX_F32 0, nullptr, pool_stage1_f32()
-#define ME_PREPARE_MATRIX_F64 0, nullptr, nullptr
+#define ME_PREPARE_MATRIX_F64 0, nullptr, pool_stage1_f64()
 #endif
 #ifdef ME_USER_HAS_REJECT
 constexpr bool kHasUserReject = true;

@@ -11,6 +11,8 @@
 #pragma once
 
 #include "me_dense_mfma.h"
+#include "me_dense_f64.h"
+#include "me_per_device.h"
 
 namespace me {
 
@@ -107,6 +109,110 @@ __global__ void __launch_bounds__(64 * kGramWaves) k_pool_gram64(const float *__
 inline hipError_t launch_pool_gram64(const void *x, long long n, double *partials, int n_rows, hipStream_t stream) {
   hipLaunchKernelGGL(k_pool_gram64<0>, dim3((unsigned)((n_rows + kGramWaves - 1) / kGramWaves)), dim3(64 * kGramWaves), 0, stream,
                      (const float *)x, n, partials, n_rows);
+  return hipGetLastError();
+}
+
+// ... and in float64 (the reference's dtype; the generic kernel: 500 us at 2^19 chains): v_mfma_f64_16x16x4_f64, lane l of
+// which holds A[row l & 15][k = l >> 4] and B[k = l >> 4][column l & 15] -- for a Gram product both are "parameter
+// 16 b + (l & 15) of chain 4 s + (l >> 4)", so ONE fragment per 16-parameter block and k step serves as A of its block
+// row and B of its block column: 4 LDS reads and the 10 lower blocks' MFMAs per step of four chains, 160 MFMAs per tile.
+// Everything is float64, so the accumulators simply run across the tiles of a wavefront.  The row sums (sum x_i,
+// sum |x_i|) come from the same fragments: a lane adds up what it reads -- the chains 4 s + (l >> 4) of its parameter --
+// and the four lane groups are added once at the end (two ds_swizzle-free __shfl_xor steps).
+constexpr int kGramPitchF64 = 68;        // doubles per parameter row: 16 rows x 4 columns of a fragment read hit 64 different 8-byte slots
+
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(64 * kGramWaves) k_pool_gram64_f64(const double *__restrict__ x, long long n,
+                                                                     double *__restrict__ partials, int n_rows) {
+  constexpr int D = 64;
+  constexpr int n_aug = 2 * D;
+  constexpr int n_entries = 1 + n_aug + D * (D + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gram_lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row_id = blockIdx.x * kGramWaves + wave;
+  if (row_id >= n_rows) return;
+  double *tile = reinterpret_cast<double *>(gram_lds) + (size_t)wave * D * kGramPitchF64;
+  const int j = lane & 15, h = lane >> 4;
+
+  f64x4 acc[10];                                 // blocks (bi, bj), bj <= bi, at index bi (bi + 1) / 2 + bj
+#pragma unroll
+  for (int b = 0; b < 10; ++b) acc[b] = f64x4{0.0, 0.0, 0.0, 0.0};
+  double sum_x[4] = {0.0, 0.0, 0.0, 0.0}, sum_abs[4] = {0.0, 0.0, 0.0, 0.0}, count = 0.0;
+
+  const long long n_tiles = (n + 63) / 64;
+  double next[D];                                // the next tile's rows, requested before the current tile is reduced
+  auto request = [&](long long t) {
+    const long long c = t * 64 + lane;
+    const bool live = t < n_tiles && c < n;
+    const long long cc = live ? c : 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const double v = x[(long long)d * n + cc];
+      next[d] = live ? v : 0.0;
+    }
+  };
+  request(row_id);
+  for (long long t = row_id; t < n_tiles; t += n_rows) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) tile[d * kGramPitchF64 + lane] = next[d];
+    request(t + n_rows);
+    count += (double)(n - t * 64 < 64 ? n - t * 64 : 64);
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      double f[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        f[b] = tile[(16 * b + j) * kGramPitchF64 + 4 * s + h];
+        sum_x[b] += f[b];
+        sum_abs[b] += __builtin_fabs(f[b]);
+      }
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+        for (int bj = 0; bj <= bi; ++bj)
+          acc[bi * (bi + 1) / 2 + bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi], f[bj], acc[bi * (bi + 1) / 2 + bj], 0, 0, 0);
+    }
+    asm volatile("" ::: "memory");               // the tile is consumed before the next one overwrites it
+  }
+
+  double *out = partials + (long long)row_id * n_entries;
+  if (lane == 0) out[0] = count;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    double sx = sum_x[b], sa = sum_abs[b];
+    sx += __shfl_xor(sx, 16);
+    sa += __shfl_xor(sa, 16);
+    sx += __shfl_xor(sx, 32);
+    sa += __shfl_xor(sa, 32);
+    if (h == 0) {
+      out[1 + 16 * b + j] = sx;
+      out[1 + D + 16 * b + j] = sa;
+    }
+  }
+  // accumulator register r of lane l is element (row h + 4 r, column j) of its block
+#pragma unroll
+  for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+    for (int bj = 0; bj <= bi; ++bj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * bi + h + 4 * r, col = 16 * bj + j;
+        if (row >= col) out[1 + n_aug + row * (row + 1) / 2 + col] = acc[bi * (bi + 1) / 2 + bj][r];
+      }
+}
+
+inline hipError_t launch_pool_gram64_f64(const void *x, long long n, double *partials, int n_rows, hipStream_t stream) {
+  constexpr size_t lds = (size_t)kGramWaves * 64 * kGramPitchF64 * sizeof(double);      // 2 x 34 KB
+  static PerDevice<int> raised;
+  int device = 0;
+  hipError_t err = hipGetDevice(&device);
+  if (err != hipSuccess) return err;
+  if (raised.get(device, [&]() -> int {
+        return hipFuncSetAttribute((const void *)k_pool_gram64_f64<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : -1;
+      }) < 0)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_pool_gram64_f64<0>, dim3((unsigned)((n_rows + kGramWaves - 1) / kGramWaves)), dim3(64 * kGramWaves), lds, stream,
+                     (const double *)x, n, partials, n_rows);
   return hipGetLastError();
 }
 

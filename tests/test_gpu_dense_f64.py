@@ -94,3 +94,26 @@ def test_dense64_f64_full_size_shard_equivalence_and_moments():
     want = 0.5 * np.linalg.inv(AMAT)
     assert np.all(np.abs(st["covariance"] - want) < 8 * np.max(np.abs(want)) * np.sqrt(2.0 / n) * 6)
     assert 0.15 < st["acceptance_rate"] < 0.5
+
+
+def test_pooled_moments_float64_gram_kernel_matches_numpy():
+    """64 real parameters in float64 pool their second moments with v_mfma_f64_16x16x4_f64 (me_pool_gram.h,
+    k_pool_gram64_f64): the result is the plain float64 sums over the chains' current states -- ragged last tile, several
+    tiles per wavefront, fewer tiles than wavefronts -- to rounding, and bitwise reproducible."""
+    from metropolisengine_amd.distributed import moments_size
+    for n in (5, 64 * 3 + 5, (1 << 16) + 64 * 7 + 9):
+        eng = me.MetropolisEngine(me.DenseQuadratic(AMAT), None, list(np.linspace(-0.5, 0.5, 64)), None, temp=1.0,
+                                  n_chains=n, seed=13, sampling_width=0.2, cov_mode="fixed", dtype="f64")
+        eng.step_all(40)
+        x = eng._get(0)
+        m = eng.pooled_moments()
+        assert m.shape == (moments_size(64, 0),)
+        acc, prop = eng.accept_stats()
+        assert m[0] == n and m[-2] == acc and m[-1] == prop
+        assert np.allclose(m[1:65], x.sum(axis=0), rtol=1e-12, atol=1e-11)
+        second = x.T @ x
+        assert np.allclose(m[65:65 + 2080], second[np.tril_indices(64)], rtol=1e-12, atol=1e-11)
+        obs = m[65 + 2080:65 + 2080 + 128]
+        assert np.allclose(obs[:64], np.abs(x).sum(axis=0), rtol=1e-12)
+        assert np.allclose(obs[64:], (x * x).sum(axis=0), rtol=1e-12)
+        assert np.array_equal(m, eng.pooled_moments())             # fixed summation order: bitwise reproducible

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import metropolisengine_amd as me
 from metropolisengine_amd.distributed import moments_size
 n = 1 << 19
-e = me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 64, None, temp=1.0, n_chains=n, seed=1, cov_mode="fixed")
+e = me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 64, None, temp=1.0, n_chains=n, seed=1, cov_mode="fixed", dtype=(sys.argv[1] if len(sys.argv) > 1 else "f32"))
 e.step_all(10); e.sync()
 size = moments_size(64, 0)
 out = np.empty(size)
