@@ -95,7 +95,7 @@ def table(dtype):
     kernel = "k_step_dense64_bf16x3" if dtype == "f32" else "k_step_dense64_f64 (v_mfma_f64_16x16x4_f64)"
     add(kernel + " (64,0)  [config 4]", 2 * 64 + 4, n4, step_us(eng, 200), "valu+mfma")
     add("k_measure (64,0): means, observables", 64 + 1 + 2 * 64 + 2 * 128, n4, measure_us(eng))
-    add("pooled_moments (64,0): stage 1 + k_pool_finish + copy", 64, n4, pooled_us(eng), "mfma" if dtype == "f32" else "latency")
+    add("pooled_moments (64,0): stage 1 + k_pool_finish + copy", 64, n4, pooled_us(eng), "mfma")
     del eng
     # config 5
     n5 = 1 << 18
