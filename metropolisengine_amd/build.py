@@ -89,9 +89,12 @@ def build(force=False, jobs=None, verbose=True):
     os.makedirs(LIB_DIR, exist_ok=True)
     headers = _headers()
     units = []
-    for nr, nc, dense, per_chain in KERNEL_DIMS:
-        units.append((os.path.join(OBJ_DIR, "me_kernels_%d_%d.o" % (nr, nc)), os.path.join(CSRC, "me_kernels.hip"),
-                      ["-DME_NR=%d" % nr, "-DME_NC=%d" % nc, "-DME_DENSE=%d" % dense, "-DME_PER_CHAIN=%d" % per_chain]))
+    # the largest sets first: they take minutes, the small ones seconds
+    for nr, nc, dense, per_chain in sorted(KERNEL_DIMS, key=lambda dims: -(dims[0] + 2 * dims[1])):
+        for bits in (32, 64):       # one object per precision: the halves of a large set (64 parameters) build in parallel
+            units.append((os.path.join(OBJ_DIR, "me_kernels_%d_%d_f%d.o" % (nr, nc, bits)), os.path.join(CSRC, "me_kernels.hip"),
+                          ["-DME_NR=%d" % nr, "-DME_NC=%d" % nc, "-DME_DENSE=%d" % dense, "-DME_PER_CHAIN=%d" % per_chain,
+                           "-DME_ONLY_DTYPE=%d" % bits]))
     for name in ("me_generic", "me_statistics", "me_runtime_dims", "me_api"):
         units.append((os.path.join(OBJ_DIR, name + ".o"), os.path.join(CSRC, name + ".hip"), []))
 
@@ -132,7 +135,17 @@ def _build_plugin(out, defines, extra_inputs, extra_includes=(), force=False):
     includes = []
     for inc in extra_includes:
         includes += ["-I", inc]
-    _run([hipcc()] + args + includes + [src, "-o", out, "-L", LIB_DIR, "-lmetropolis_hip", "-Wl,-rpath,$ORIGIN"], out, key)
+    # one object per precision, compiled side by side (a large set is minutes of hipcc per precision), then the link
+    compile_args = [a for a in args if a != "-shared"] + includes
+    objs = [os.path.join(OBJ_DIR, os.path.basename(out) + ".f%d.o" % bits) for bits in (32, 64)]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=2) as pool:
+        jobs = [pool.submit(_run, [hipcc()] + compile_args + ["-DME_ONLY_DTYPE=%d" % bits, "-c", src, "-o", obj])
+                for bits, obj in zip((32, 64), objs)]
+        for job in jobs:
+            job.result()
+    _run([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs +
+         ["-L", LIB_DIR, "-lmetropolis_hip", "-Wl,-rpath,$ORIGIN"], out, key)
     return out
 
 

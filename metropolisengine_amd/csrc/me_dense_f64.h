@@ -136,6 +136,7 @@ __device__ __forceinline__ void wave_tri_product_64(const Frags &frags, const do
 template <int CK>
 __global__ void __launch_bounds__(kDense64F64Threads, 2)
     k_step_dense64_f64(StepArgs<double> a, const double *__restrict__ t_image, const double *__restrict__ l_image) {
+  constexpr int kRngUnroll = CK == CK_SHARED ? 1 : ME_DENSE64_F64_RNG_UNROLL;
   constexpr int D = 64, H = 32;          // H rows per lane
   using N_ = Num<double>;
   extern __shared__ __attribute__((aligned(16))) double smem64[];
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(kDense64F64Threads, 2)
       // the fragment reads of T are loop-invariant (80 registers if hoisted out of the sweep loop): keep them here
       asm volatile("" ::: "memory");
       // ---- this lane's 32 normals (Philox blocks 8 half .. 8 half + 7, two Box-Muller pairs each) -> LDS; a rolled loop
-#pragma unroll (CK == CK_SHARED ? 1 : ME_DENSE64_F64_RNG_UNROLL)
+#pragma unroll kRngUnroll
       for (int k = 0; k < 8; ++k) {
         const int b = 8 * half + k;
         U4 ctr;

@@ -118,7 +118,6 @@ template <typename R, int NR, bool NT>
 __global__ void __launch_bounds__((FactorTile<R, NR>::kThreads))
 k_factor_tile(const R *cov, R *factor, unsigned int *status, long long n) {
   using T = FactorTile<R, NR>;
-  using N_ = Num<R>;
   constexpr int P = T::P, PS = T::PS, G = T::kChains, LPC = T::LPC, RPL = T::RPL;
   constexpr int kGroupsPerTile = 64 / G;
   constexpr int kRowsPerPass = T::kThreads / G;      // entries a copy pass of the workgroup covers

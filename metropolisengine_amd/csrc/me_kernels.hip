@@ -163,7 +163,15 @@ hipError_t launch_step_cov(const StepLaunch &l, const StepArgs<R> &a, const Ener
   switch (l.cov_kind) {
     case CK_IDENTITY: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_IDENTITY, INJECT, GROUP>), grid, block, 0, stream, a, en); break;
     case CK_SHARED: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_SHARED, INJECT, GROUP>), grid, block, 0, stream, a, en); break;
-#if ME_PER_CHAIN
+#if ME_PER_CHAIN == 2
+    case CK_PER_CHAIN: {
+      // streamed factors (8-37 KB per chain and step) never stay in any cache: one variant, read non-temporally.  (The
+      // stream is thousands of lines of straight-line code per instantiation; the replay hook does not get one.)
+      if constexpr (INJECT) return hipErrorInvalidValue;
+      else hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_PER_CHAIN_NT, INJECT, GROUP>), grid, block, 0, stream, a, en);
+      break;
+    }
+#elif ME_PER_CHAIN
     case CK_PER_CHAIN: {
       // Launches whose working set (state + packed factor) cannot stay in the Infinity Cache read the factor
       // non-temporally (CK_PER_CHAIN_NT): streamed with the default policy it evicts the chain state, which then goes to
@@ -442,7 +450,7 @@ hipError_t prepare_matrix_f32(const void *factor_full, void *image, hipStream_t 
   }
   return hipSuccess;
 }
-constexpr size_t kMatrixImageBytes = (NR == 64 && NC == 0) ? sizeof(unsigned int) * kBf16FragWords : 0;
+[[maybe_unused]] constexpr size_t kMatrixImageBytes = (NR == 64 && NC == 0) ? sizeof(unsigned int) * kBf16FragWords : 0;
 #define ME_PREPARE_MATRIX_F32 kMatrixImageBytes, (kMatrixImageBytes ? prepare_matrix_f32 : nullptr), pool_stage1_f32()
 hipError_t prepare_matrix_f64(const void *matrix, void *image, hipStream_t stream) {
   if constexpr (NR == 64 && NC == 0) {
@@ -451,7 +459,7 @@ hipError_t prepare_matrix_f64(const void *matrix, void *image, hipStream_t strea
   }
   return hipSuccess;
 }
-constexpr size_t kMatrixImageBytesF64 = (NR == 64 && NC == 0) ? sizeof(double) * kDense64F64ImageDoubles : 0;
+[[maybe_unused]] constexpr size_t kMatrixImageBytesF64 = (NR == 64 && NC == 0) ? sizeof(double) * kDense64F64ImageDoubles : 0;
 #define ME_PREPARE_MATRIX_F64 kMatrixImageBytesF64, (kMatrixImageBytesF64 ? prepare_matrix_f64 : nullptr), pool_stage1_f64()
 #else
 #define ME_PREPARE_MATRIX_F32 0, nullptr, pool_stage1_f32()
@@ -462,17 +470,30 @@ constexpr bool kHasUserReject = true;
 #else
 constexpr bool kHasUserReject = false;
 #endif
+// ME_ONLY_DTYPE=32 / 64 compiles one precision of the set (build.py splits the main library's sets in two objects so
+// that the two halves build in parallel; plugins are one object)
+#ifndef ME_ONLY_DTYPE
+#define ME_ONLY_DTYPE 0
+#endif
+#if ME_ONLY_DTYPE != 64
 const KernelSet kSetF32 = {ME_SET_NAME, ME_F32, NR, NC, ME_PER_CHAIN != 0, (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0), has_energy, energy_terms, step<float>,
                            (NC > 0 && ME_PER_CHAIN == 1) ? magphase<float> : nullptr, measure<float>, init_energy<float>,
                            ME_PREPARE_MATRIX_F32, kHasUserReject, ME_PER_CHAIN == 2};
+#endif
+#if ME_ONLY_DTYPE != 32
 const KernelSet kSetF64 = {ME_SET_NAME, ME_F64, NR, NC, ME_PER_CHAIN != 0, (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0), has_energy, energy_terms, step<double>,
                            (NC > 0 && ME_PER_CHAIN == 1) ? magphase<double> : nullptr, measure<double>, init_energy<double>,
                            ME_PREPARE_MATRIX_F64, kHasUserReject, ME_PER_CHAIN == 2};
+#endif
 
 struct Registrar {
   Registrar() {
+#if ME_ONLY_DTYPE != 64
     register_kernel_set(&kSetF32);
+#endif
+#if ME_ONLY_DTYPE != 32
     register_kernel_set(&kSetF64);
+#endif
   }
 } registrar;
 
