@@ -51,6 +51,14 @@ namespace me {
 // rows per lane for more than 32 parameters.  Measured at 64 parameters x 2^19 chains, whole measure(): float32 10.4 ms with
 // one row, 7.8 ms with two; float64 16.3 ms with one, 19.8 ms with two (2 x 64 doubles = 256 registers per lane leave one
 // wavefront per SIMD, and the latencies of the column recurrence are no longer hidden)
+// every N-th pair of broadcasts through v_readlane instead of LDS (0: none); one matrix per wavefront, one row per lane only.
+// float64, whole measure() at 64 parameters x 2^19 chains: none 16.35 ms, every pair 15.33, every 2nd 14.96, every 3rd 14.78
+#ifndef ME_FACTOR_TILE_READLANE_F32
+#define ME_FACTOR_TILE_READLANE_F32 0
+#endif
+#ifndef ME_FACTOR_TILE_READLANE_F64
+#define ME_FACTOR_TILE_READLANE_F64 3
+#endif
 #ifndef ME_FACTOR_TILE_ROWS_PER_LANE_F32
 #define ME_FACTOR_TILE_ROWS_PER_LANE_F32 2
 #endif
@@ -223,6 +231,7 @@ k_factor_tile(const R *cov, R *factor, unsigned int *status, long long n) {
         const int row = my_row + r * LPC;
         a[r][k] = (k <= row && row < NR) ? mine[col(k) + row - k] : R(0);
       }
+    constexpr int kReadlane = (T::CPW == 1 && RPL == 1) ? (sizeof(R) == 4 ? ME_FACTOR_TILE_READLANE_F32 : ME_FACTOR_TILE_READLANE_F64) : 0;
     static_for<NR>([&](auto column) {
       constexpr int j = decltype(column)::value;
       constexpr int r0 = j / LPC;            // row blocks below r0 are finished: rows r LPC .. r LPC + LPC - 1 < j
@@ -234,7 +243,18 @@ k_factor_tile(const R *cov, R *factor, unsigned int *status, long long n) {
       }
 #pragma unroll
       for (int k = 0; k + 1 < j; k += 2) {
-        const R l0 = mine[col(k) + j - k], l1 = mine[col(k + 1) + j - k - 1];
+        // L_jk for the whole group: a broadcast read of LDS -- or, with one matrix per wavefront and one row per lane, lane
+        // j's own register k through v_readlane.  The LDS read costs LDS bandwidth (64 lanes x 8 bytes whatever the
+        // address pattern), the readlane two vector instructions in float64: taking every ME_FACTOR_TILE_READLANE-th pair
+        // from the registers balances the two pipes.
+        R l0, l1;
+        if (kReadlane > 0 && (k / 2) % (kReadlane > 0 ? kReadlane : 1) == kReadlane - 1) {
+          l0 = lane_value(a[0][k], j, true);
+          l1 = lane_value(a[0][k + 1], j, true);
+        } else {
+          l0 = mine[col(k) + j - k];
+          l1 = mine[col(k + 1) + j - k - 1];
+        }
 #pragma unroll
         for (int r = r0; r < RPL; ++r) {
           s0[r] -= a[r][k] * l0;

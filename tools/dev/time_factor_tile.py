@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 import metropolisengine_amd as me
 n_log2 = int(sys.argv[1]) if len(sys.argv) > 1 else 19
-for dtype in ("f32", "f64"):
+for dtype in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("f32", "f64")):
     n = 1 << n_log2
     e = me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 64, None, temp=1.0, n_chains=n, seed=2026, dtype=dtype, sampling_width=0.2, cov_mode="reference")
     for _ in range(52):
