@@ -33,6 +33,9 @@
 // 2 MB of LDS traffic per chain, 6.8 ms at 128 bytes per clock and CU.  Two rows per lane and two chains per wavefront
 // halve the broadcasts per matrix: float32 measure() 10.4 -> 7.8 ms; float64 would need 2 x 128 registers for the rows
 // alone and loses more to occupancy than it gains (16.3 -> 19.8 ms), so it keeps one row per lane.
+// Tried and dropped: requesting the NEXT unit's entries into registers before the factorization (33 doubles per thread;
+// 256 registers, no scratch): float64 measure() 14.8 -> 16.9 ms; folding the covariance recursion into the load phase
+// (one pass over C fewer): 14.8 -> 15.1 ms.
 // History: LDS row-major with the pivot through LDS and IEEE sqrt + division 17 ms (float64); column-major, readlane
 // pivot, sqrt_and_inverse 10 ms; XCD-aware order: -15 % where a run is half a sector (32 bytes).
 #pragma once

@@ -80,6 +80,16 @@ def test_other_streamed_sizes_follow_the_oracle(nr):
     assert np.allclose(eng._get(0), ora.x, rtol=0, atol=1e-8)
     assert np.allclose(eng.energy_total, ora.energy, rtol=0, atol=1e-8)
     assert eng.accept_stats() == (ora.accepted, ora.proposed)
+    # the float32 build of the same kernels: its factors reproduce its covariance, chain by chain
+    f32 = me.MetropolisEngine(me.DiagQuadratic(weights), None, x0, None, temp=1.0, n_chains=n, seed=seed, dtype="f32",
+                              sampling_width=0.1, cov_mode="reference")
+    for k in range(54):
+        f32.step_all(2)
+        f32.measure()
+    f32.step_all(3)
+    fr, _ = f32.proposal_factors()
+    assert np.allclose(fr @ np.swapaxes(fr, 1, 2), f32.covariance_matrix_real, rtol=2e-4, atol=2e-5)
+    assert np.allclose(f32.covariance_matrix_real, eng.covariance_matrix_real, rtol=0, atol=5e-3)   # same streams, near-equal paths
 
 
 def test_64_real_per_chain_shapes_float32_shards_and_state():
