@@ -13,9 +13,10 @@
 //   k_measure_runtime, k_init_energy_runtime: the same loops over d for the running means / observables / energy.
 //
 //   k_step_runtime_lds  what cannot stream: a DENSE quadratic form needs all of x' at once, a SHARED proposal factor all of
-//                    g.  Both are parked in LDS ([D][64 lanes], one wavefront per block); the two O(D^2) triangle
-//                    products are register-blocked 16 x 16 with the tiles of T (folded triangle of A, T_ij = A_ij + A_ji,
-//                    or the packed factor L) loaded coalesced and handed around by v_readlane (tri_rows_blocked).
+//                    g.  Both are parked in LDS ([D][64 lanes], one wavefront per block) and the two O(D^2) triangle
+//                    products run on the matrix cores (tri_rows_mfma: Y = T V for the wavefront's 64 chains with
+//                    v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32, T = folded triangle of A, T_ij = A_ij + A_ji, or
+//                    the packed factor L, gathered from global memory as the A operand, V from LDS as the B operand).
 //                    Limits: the LDS a block may use (D <= ~290 in float64 with the identity shape, ~145 with a shared
 //                    factor; twice that in float32).
 //
@@ -31,6 +32,10 @@
 namespace me {
 namespace {
 
+// triangle products of the LDS-resident kernel: 1 = matrix cores (tri_rows_mfma), 0 = VALU with v_readlane broadcasts
+#ifndef ME_RUNTIME_MFMA
+#define ME_RUNTIME_MFMA 1
+#endif
 constexpr size_t kRuntimeLdsLimit = 150 * 1024;      // dynamic LDS a block of the LDS-resident step kernel may ask for
 
 template <typename R>
@@ -254,6 +259,63 @@ __device__ __forceinline__ void tri_rows_blocked(const R *__restrict__ tri_packe
   }
 }
 
+// The same triangle product on the matrix cores: Y = T V for the 64 chains of a wavefront is a (D x D) x (D x 64) product.
+// v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32: lane l holds A[row l & 15][k = l >> 4] -- T[i0 + (l & 15)][k0 + (l >> 4)],
+// one gathered load from the packed triangle (zero above the diagonal and past row D) -- and B[k = l >> 4][column l & 15] --
+// V[k0 + (l >> 4)][chain 16 cb + (l & 15)], one conflict-free LDS read per 16-chain block cb.  A row block of 16 rows
+// costs 4 (ib + 1) k steps of 4 MFMAs; T reaches the arithmetic without any broadcast.  The results arrive with the chain
+// on the lane's low four bits and four rows in the registers (float64: row (l >> 4) + 4 r, float32: row 4 (l >> 4) + r);
+// done(row, cb, value) is called for each of them with (row, chain 16 cb + (l & 15)).
+template <typename R>
+struct MfmaTile;
+template <>
+struct MfmaTile<double> {
+  using Acc = __attribute__((ext_vector_type(4))) double;
+  static __device__ __forceinline__ Acc mma(double a, double b, Acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <>
+struct MfmaTile<float> {
+  using Acc = __attribute__((ext_vector_type(4))) float;
+  static __device__ __forceinline__ Acc mma(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
+template <typename R, class Done>
+__device__ __forceinline__ void tri_rows_mfma(const R *__restrict__ tri_packed, R (*v)[kStepThreads], int D, int lane, Done &&done) {
+  using M = MfmaTile<R>;
+  const int j = lane & 15, h = lane >> 4;
+  for (int i0 = 0; i0 < D; i0 += 16) {
+    typename M::Acc acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = typename M::Acc{R(0), R(0), R(0), R(0)};
+    const int i = i0 + j;                                   // this lane's row of T
+    const R *trow = tri_packed + (size_t)(i < D ? i : D - 1) * (size_t)((i < D ? i : D - 1) + 1) / 2;
+    for (int k0 = 0; k0 < i0 + 16; k0 += 16) {              // four k steps at a time: their A loads first
+      R a4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = k0 + 4 * q + h;
+        a4[q] = (k <= i && i < D) ? trow[k] : R(0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int k = k0 + 4 * q + h;
+        if (k >= D) k = D - 1;                              // past the triangle A is zero: any finite V will do
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[cb] = M::mma(a4[q], v[k][16 * cb + j], acc[cb]);
+      }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = i0 + M::row(lane, r);
+        if (row < D) done(row, cb, acc[cb][r]);
+      }
+  }
+}
+
 template <typename R, bool SHARED>
 __global__ void __launch_bounds__(kStepThreads) k_step_runtime_lds(StepArgs<R> a, RuntimeStep<R> p, const R *__restrict__ folded) {
   using N_ = Num<R>;
@@ -297,12 +359,13 @@ __global__ void __launch_bounds__(kStepThreads) k_step_runtime_lds(StepArgs<R> a
       const R s_r = w_r, s_c = w_c * R(0.70710678118654752440);
       // ---- the state into x' first, sixteen loads in flight at a time (issued one by one where they are used, every
       // load would expose the whole memory latency: one wavefront per SIMD has nothing else to run)
-      for (int d0b = 0; d0b < D; d0b += 16) {
-        R xd[16];
+      constexpr int kStateBatch = 16;      // (64 at a time changed nothing)
+      for (int d0b = 0; d0b < D; d0b += kStateBatch) {
+        R xd[kStateBatch];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) xd[t] = d0b + t < D ? xc[(long long)(d0b + t) * n] : R(0);
+        for (int t = 0; t < kStateBatch; ++t) xd[t] = d0b + t < D ? xc[(long long)(d0b + t) * n] : R(0);
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
+        for (int t = 0; t < kStateBatch; ++t)
           if (d0b + t < D) xp[d0b + t][lane] = xd[t];
       }
       // ---- the normals: straight into x' (identity shape) or parked (shared factor)
@@ -322,12 +385,36 @@ __global__ void __launch_bounds__(kStepThreads) k_step_runtime_lds(StepArgs<R> a
       }
       if constexpr (SHARED) {
         // x' = x + w L g, row by row; L packed lower triangle (pure real spaces: nc == 0)
-        tri_rows_blocked(a.factor, gs, D, lane, [&](int i, R acc, R) { xp[i][lane] = fma_(s_r, acc, xp[i][lane]); });
+        if (ME_RUNTIME_MFMA) {
+          R s_col[4];                                       // the widths of the chains this lane holds results for
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) s_col[cb] = __shfl(s_r, 16 * cb + (lane & 15));
+          tri_rows_mfma(a.factor, gs, D, lane, [&](int row, int cb, R y) {
+            const int col = 16 * cb + (lane & 15);
+            xp[row][col] = fma_(s_col[cb], y, xp[row][col]);      // every (row, chain) is touched by exactly one lane
+          });
+        } else {
+          tri_rows_blocked(a.factor, gs, D, lane, [&](int i, R acc, R) { xp[i][lane] = fma_(s_r, acc, xp[i][lane]); });
+        }
       }
       // ---- energy of the proposal
       R e_new = R(0);
       if (p.energy_kind == ME_ENERGY_DENSE_QUAD) {
-        tri_rows_blocked(folded, xp, D, lane, [&](int, R y, R xi) { e_new += xi * y; });
+        if (ME_RUNTIME_MFMA) {
+          // E = sum_i x'_i y_i: a lane adds up the rows it holds for its chain of each 16-chain block, the four lane
+          // groups are added, and lane l keeps the block of its own chain, cb = l >> 4
+          R part[4] = {R(0), R(0), R(0), R(0)};
+          tri_rows_mfma(folded, xp, D, lane, [&](int row, int cb, R y) { part[cb] = fma_(xp[row][16 * cb + (lane & 15)], y, part[cb]); });
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) {
+            part[cb] += __shfl_xor(part[cb], 16);
+            part[cb] += __shfl_xor(part[cb], 32);
+          }
+          const int own = lane >> 4;
+          e_new = own == 0 ? part[0] : own == 1 ? part[1] : own == 2 ? part[2] : part[3];
+        } else {
+          tri_rows_blocked(folded, xp, D, lane, [&](int, R y, R xi) { e_new += xi * y; });
+        }
       } else {
         for (int d = 0; d < D; ++d) e_new += weight_of(p, d) * xp[d][lane] * xp[d][lane];
       }
