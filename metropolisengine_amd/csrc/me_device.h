@@ -286,12 +286,31 @@ struct EnergyDense {  // x^T A x, A[D][D] row-major in device memory
     return t;
   }
   __device__ __forceinline__ void prepare() const {
+    // Eight entries per thread at a time, their loads issued together: at D = 64 a one-sweep launch of 64-thread
+    // workgroups spends 33 rounds per wavefront here, and one entry per round (row found by counting up, two dependent
+    // loads) cost ~60 us per wavefront -- a third of k_step's time with streamed per-chain factors.
     R *t = folded();
-    for (int k = threadIdx.x; k < PT; k += blockDim.x) {
-      int i = 0;
-      while ((i + 1) * (i + 2) / 2 <= k) ++i;
-      const int j = k - i * (i + 1) / 2;
-      t[k] = i == j ? a[i * D + i] : a[i * D + j] + a[j * D + i];
+    constexpr int kBatch = 8;
+    for (int k0 = threadIdx.x; k0 < PT; k0 += kBatch * (int)blockDim.x) {
+      R lo[kBatch], hi[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int k = k0 + u * (int)blockDim.x;
+        lo[u] = hi[u] = R(0);
+        if (k < PT) {
+          int i = (int)((__builtin_sqrtf((float)(8 * k + 1)) - 1.0f) * 0.5f);     // row of packed entry k
+          if ((i + 1) * (i + 2) / 2 <= k) ++i;
+          if (i * (i + 1) / 2 > k) --i;
+          const int j = k - i * (i + 1) / 2;
+          lo[u] = a[i * D + j];
+          if (i != j) hi[u] = a[j * D + i];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int k = k0 + u * (int)blockDim.x;
+        if (k < PT) t[k] = lo[u] + hi[u];
+      }
     }
     __syncthreads();
   }

@@ -207,9 +207,10 @@ hipError_t launch_step_group(const StepLaunch &l, const StepArgs<R> &a, const En
 template <typename R, class Energy>
 hipError_t step_with(const StepLaunch &l, const Energy &en, hipStream_t stream) {
   const StepArgs<R> a = typed<R>(l);
-  // fused sweeps run in 256-thread blocks; the streamed per-chain factor path parks its normals in LDS sized for 64
+  // fused sweeps run in 256-thread blocks, and so does the streamed per-chain factor path at any sweep count: its
+  // wavefronts run one per SIMD anyway, and four of them share one copy of the energy's LDS tables
   const bool per_chain = l.cov_kind == CK_PER_CHAIN;
-  const int threads = (l.n_sweeps >= kFusedSweepsThreshold && !(ME_PER_CHAIN == 2 && per_chain)) ? kFusedStepThreads : kStepThreads;
+  const int threads = (l.n_sweeps >= kFusedSweepsThreshold || (ME_PER_CHAIN == 2 && per_chain)) ? kFusedStepThreads : kStepThreads;
   const dim3 grid(grid_for(l.n, l.grid_blocks, threads)), block(threads);
   if (l.inj_normals) {
     // injected-stream replay: float64 only (it exists to check trajectories against the float64 reference)
