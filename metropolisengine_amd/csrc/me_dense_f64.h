@@ -144,7 +144,15 @@ __global__ void __launch_bounds__(kDense64F64Threads, 2)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double *xp = smem64 + kDense64F64ImageDoubles + wave * kDense64F64WaveDoubles;
   double *exch = xp + D * kTileChains64;
-  for (int idx = threadIdx.x; idx < kDense64F64ImageDoubles; idx += kDense64F64Threads) lds_t[idx] = t_image[idx];
+  {   // the image in one batch of loads (a rolled copy loop waits for every load before it issues the next)
+    constexpr int kPieces = kDense64F64ImageDoubles / kDense64F64Threads;
+    static_assert(kPieces * kDense64F64Threads == kDense64F64ImageDoubles, "the image divides evenly over the workgroup");
+    double piece[kPieces];
+#pragma unroll
+    for (int k = 0; k < kPieces; ++k) piece[k] = t_image[k * kDense64F64Threads + threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < kPieces; ++k) lds_t[k * kDense64F64Threads + threadIdx.x] = piece[k];
+  }
   N_::prepare();    // the log table of the float64 Box-Muller; ends with the block barrier that also covers lds_t
 
   const int j = lane & 15, h = lane >> 4;                 // position in the MFMA result blocks

@@ -92,9 +92,18 @@ struct Num<double> {
   // once per block, by every thread, before the first normal_pair
   static __device__ __forceinline__ void prepare() {
     double(*table)[2] = log_table();
-    for (int k = threadIdx.x; k < math64::kLogEntries; k += blockDim.x) {
-      table[k][0] = math64::kLogTable[k][0];
-      table[k][1] = math64::kLogTable[k][1];
+    // both rounds of a 64-thread workgroup's share in one batch of loads (a rolled copy loop waits for each load in turn)
+    for (int k0 = threadIdx.x; k0 < math64::kLogEntries; k0 += 2 * (int)blockDim.x) {
+      const int k1 = k0 + (int)blockDim.x;
+      const bool second = k1 < math64::kLogEntries;
+      const double a0 = math64::kLogTable[k0][0], a1 = math64::kLogTable[k0][1];
+      const double b0 = second ? math64::kLogTable[k1][0] : 0.0, b1 = second ? math64::kLogTable[k1][1] : 0.0;
+      table[k0][0] = a0;
+      table[k0][1] = a1;
+      if (second) {
+        table[k1][0] = b0;
+        table[k1][1] = b1;
+      }
     }
     __syncthreads();
   }
