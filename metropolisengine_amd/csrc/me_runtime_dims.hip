@@ -291,20 +291,35 @@ __device__ __forceinline__ void tri_rows_mfma(const R *__restrict__ tri_packed, 
     for (int cb = 0; cb < 4; ++cb) acc[cb] = typename M::Acc{R(0), R(0), R(0), R(0)};
     const int i = i0 + j;                                   // this lane's row of T
     const R *trow = tri_packed + (size_t)(i < D ? i : D - 1) * (size_t)((i < D ? i : D - 1) + 1) / 2;
-    for (int k0 = 0; k0 < i0 + 16; k0 += 16) {              // four k steps at a time: their A loads first
-      R a4[4];
+    // Sixteen columns (four k steps) at a time.  Their operands are requested as a batch BEFORE the sixteen MFMAs: the A
+    // gathers one block ahead, the sixteen LDS reads of B in one go (left to the compiler, every pair of MFMAs waited for its
+    // own ds_read: the matrix cores idled through an LDS latency every 64 cycles; PMC: 56 % of the wavefront in s_waitcnt)
+    auto load_a = [&](int k0, R (&a4)[4]) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int k = k0 + 4 * q + h;
         a4[q] = (k <= i && i < D) ? trow[k] : R(0);
       }
+    };
+    R a_now[4], a_next[4];
+    load_a(0, a_now);
+    for (int k0 = 0; k0 < i0 + 16; k0 += 16) {
+      load_a(k0 + 16, a_next);                              // (columns past the row are zero without a load)
+      R b[4][4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         int k = k0 + 4 * q + h;
         if (k >= D) k = D - 1;                              // past the triangle A is zero: any finite V will do
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) acc[cb] = M::mma(a4[q], v[k][16 * cb + j], acc[cb]);
+        for (int cb = 0; cb < 4; ++cb) b[q][cb] = v[k][16 * cb + j];
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[cb] = M::mma(a_now[q], b[q][cb], acc[cb]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a_now[q] = a_next[q];
     }
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb)
