@@ -241,6 +241,23 @@ __device__ __forceinline__ void packed_store(const F &f, int row, unsigned int c
   else f.store(row, chain_off, value);
 }
 
+// The chain state (x, energy ledger, width) as k_step sees it.  NTS: read and written non-temporally -- chosen by the
+// launcher when the state alone is larger than the Infinity Cache, so that nothing of it could stay resident from launch to
+// launch anyway (float64, 16 parameters: 236 -> 227 us at 2^22 chains; at 2^20, where the state DOES stay resident, the
+// same policy costs 50.6 -> 59.1 us).
+template <typename R, bool NTS>
+struct StateField : Field<R> {
+  using Field<R>::Field;
+  __device__ __forceinline__ R load(int row, unsigned int chain_off) const {
+    if constexpr (NTS) return Field<R>::load_nt(row, chain_off);
+    else return Field<R>::load(row, chain_off);
+  }
+  __device__ __forceinline__ void store(int row, unsigned int chain_off, R value) const {
+    if constexpr (NTS) Field<R>::store_nt(row, chain_off, value);
+    else Field<R>::store(row, chain_off, value);
+  }
+};
+
 // packed sizes up to this are kept in registers by the per-chain factor kernels (build.py: MAX_PACKED_IN_REGISTERS)
 constexpr int kMaxPackedInRegisters = 160;
 
@@ -433,12 +450,14 @@ struct EnergyLedger {
     if constexpr (T == 1 || GROUP == GROUP_ALL) return true;
     else return (Energy::term_groups(t) & (GROUP == GROUP_REAL ? 1u : 2u)) != 0u;
   }
-  __device__ __forceinline__ void load(const Field<R> &fe, unsigned int coff) {
+  template <class F>
+  __device__ __forceinline__ void load(const F &fe, unsigned int coff) {
 #pragma unroll
     for (int t = 0; t < T; ++t)
       if (moves(t)) term[t] = fe.load(t, coff);
   }
-  __device__ __forceinline__ void store(const Field<R> &fe, unsigned int coff) const {
+  template <class F>
+  __device__ __forceinline__ void store(const F &fe, unsigned int coff) const {
 #pragma unroll
     for (int t = 0; t < T; ++t)
       if (moves(t)) fe.store(t, coff, term[t]);
@@ -537,7 +556,7 @@ __device__ __forceinline__ void static_for(F &&fn) {
 // Widths of mixed engines are three rows [sampling_width, real group, complex group] (:93-99, :429-456):
 // step_all adapts row 0 and mirrors it into the group widths (:436-437), a group step adapts only its own row.
 
-template <typename R, int NR, int NC, class Energy, int CK, bool INJECT = false, int GROUP = GROUP_ALL>
+template <typename R, int NR, int NC, class Energy, int CK, bool INJECT = false, int GROUP = GROUP_ALL, bool NTS = false>
 __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   constexpr int D = NR + 2 * NC;
   constexpr int PR = NR * (NR + 1) / 2;
@@ -555,7 +574,7 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   bool bad_energy = false, bad_width = false;
   const long long stride = (long long)gridDim.x * blockDim.x;   // 64 threads per block, or 256 for fused sweeps
   using Ledger = EnergyLedger<R, Energy, GROUP>;
-  const Field<R> fx(a.x, a.n, D), fe(a.energy, a.n, Ledger::T + (MIXED ? 1 : 0)), fw(a.width, a.n, MIXED ? 3 : 1);
+  const StateField<R, NTS> fx(a.x, a.n, D), fe(a.energy, a.n, Ledger::T + (MIXED ? 1 : 0)), fw(a.width, a.n, MIXED ? 3 : 1);
   // The reference keeps TWO ledgers: step_all of a mixed engine decides against `energy_total` and
   // updates only that (metropolis_engine.py:252-255); group steps use `energy[term]` (:214-221, :230-237).  With
   // ME_FLAG_REFERENCE_ENERGY_LEDGERS the total lives in ledger row T and this kernel touches only the rows the

@@ -161,7 +161,18 @@ template <typename R, class Energy, bool INJECT, int GROUP>
 hipError_t launch_step_cov(const StepLaunch &l, const StepArgs<R> &a, const Energy &en, dim3 grid, dim3 block,
                            hipStream_t stream) {
   switch (l.cov_kind) {
-    case CK_IDENTITY: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_IDENTITY, INJECT, GROUP>), grid, block, 0, stream, a, en); break;
+    case CK_IDENTITY: {
+      // a state that cannot stay in the Infinity Cache between launches is streamed non-temporally (StateField)
+      constexpr long long state_bytes = (long long)sizeof(R) * (D + 2);
+      if constexpr (!INJECT && GROUP == GROUP_ALL) {
+        if (state_bytes * l.n > cache_budget_bytes()) {
+          hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_IDENTITY, INJECT, GROUP, true>), grid, block, 0, stream, a, en);
+          break;
+        }
+      }
+      hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_IDENTITY, INJECT, GROUP>), grid, block, 0, stream, a, en);
+      break;
+    }
     case CK_SHARED: hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_SHARED, INJECT, GROUP>), grid, block, 0, stream, a, en); break;
 #if ME_PER_CHAIN == 2
     case CK_PER_CHAIN: {

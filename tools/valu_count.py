@@ -17,7 +17,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DTYPE = "d" if "--f64" in sys.argv else "f"        # --f64: the reference-precision instantiation
-KERNEL = "_ZN2me6k_stepI%sLi16ELi0ENS_9EnergyIsoI%sLi16ELi0EEELi0ELb0ELi0EEEvNS_8StepArgsIT_EET2_" % (DTYPE, DTYPE)
+KERNEL = "_ZN2me6k_stepI%sLi16ELi0ENS_9EnergyIsoI%sLi16ELi0EEELi0ELb0ELi0ELb0EEEvNS_8StepArgsIT_EET2_" % (DTYPE, DTYPE)
 
 with tempfile.TemporaryDirectory() as tmp:
     out = os.path.join(tmp, "k16.s")
