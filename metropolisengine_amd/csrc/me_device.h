@@ -242,8 +242,8 @@ __device__ __forceinline__ void packed_store(const F &f, int row, unsigned int c
 }
 
 // The chain state (x, energy ledger, width) as k_step sees it.  NTS: read and written non-temporally -- chosen by the
-// launcher when the state alone is larger than the Infinity Cache, so that nothing of it could stay resident from launch to
-// launch anyway (float64, 16 parameters: 236 -> 227 us at 2^22 chains; at 2^20, where the state DOES stay resident, the
+// launcher when the state alone is more than twice the Infinity Cache, so that next to nothing of it could stay resident
+// from launch to launch anyway (float64, 16 parameters: 236 -> 227 us at 2^22 chains; at 2^20, where the state DOES stay resident, the
 // same policy costs 50.6 -> 59.1 us).
 template <typename R, bool NTS>
 struct StateField : Field<R> {

@@ -162,10 +162,12 @@ hipError_t launch_step_cov(const StepLaunch &l, const StepArgs<R> &a, const Ener
                            hipStream_t stream) {
   switch (l.cov_kind) {
     case CK_IDENTITY: {
-      // a state that cannot stay in the Infinity Cache between launches is streamed non-temporally (StateField)
+      // A state far beyond the Infinity Cache is streamed non-temporally (StateField).  The threshold is TWICE the cache
+      // budget: 16 parameters at 2^22 chains, float32 (302 MB: a good part still hits) 107 us default / 114 us nt;
+      // float64 (604 MB) 236 us default / 225 us nt.
       constexpr long long state_bytes = (long long)sizeof(R) * (D + 2);
       if constexpr (!INJECT && GROUP == GROUP_ALL) {
-        if (state_bytes * l.n > cache_budget_bytes()) {
+        if (state_bytes * l.n > 2 * cache_budget_bytes()) {
           hipLaunchKernelGGL((k_step<R, NR, NC, Energy, CK_IDENTITY, INJECT, GROUP, true>), grid, block, 0, stream, a, en);
           break;
         }
