@@ -68,7 +68,9 @@ def issue_utilisation(torch, device, chain_sweeps_per_second, suffix=""):
     simds = props.multi_processor_count * 4
     busy = chain_sweeps_per_second / 64.0 * valu * 4.0
     return {"valu_per_wavefront_sweep": valu, "simds": simds, "clock_GHz": clock_hz / 1e9,
-            "frac": busy / (simds * clock_hz)}
+            "frac": busy / (simds * clock_hz),
+            "note": "LOWER BOUND on vector-pipe occupancy, not a utilisation: static VALU count x 4 cycles per wave64 "
+                    "instruction; float64, transcendental and 64-bit integer instructions take longer than 4 cycles"}
 
 
 def cgroup_cpu_quota():
@@ -146,67 +148,95 @@ def cpu_baseline_c(seconds):
                       "acceptance %.3f" % (done, dt, chains.accepted / chains.proposed)}
 
 
-def other_configs(me, device, chains_log2):
-    """Informational side measurements (not the headline): the protocols of BASELINE.json configs 3-5,
-    each through the public API incl. measure() launches; config 4 in float32 (split-bf16 matrix cores) and float64
-    (v_mfma_f64_16x16x4_f64)."""
+def other_configs(me, rank, world, device, chains_log2, reduce_max, backend, native_comm):
+    """BASELINE.json configs 3-5 through their protocols at ANY rank count: every rank owns the same
+    number of chains (weak scaling, chain_offset = rank x chains), times are the maximum over ranks, rates whole-job.
+    config 4 = 64 real parameters, dense SPD form on the matrix cores, 2^19 chains PER RANK, identity shape and
+    cov_mode="pooled" (one adapt_pooled_shape = one all-reduce, then timed steps), both dtypes; config 5 = user plugin +
+    wall, 2^18 chains per rank, (10 x step_all + measure + pooled all-reduce) x 200 with the reduction inside every
+    cycle and in its overlapped form (metropolisengine_amd/protocols.py).  ``backend`` names the all-reduce path
+    (``"rccl-native"``: the engine's own RCCL communicator, ``native_comm(engine)`` creates it; ``None``:
+    torch.distributed)."""
     import numpy as np
+    from metropolisengine_amd import protocols
     out = {}
     n = 1 << chains_log2
 
+    def guarded(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as exc:                        # a side measurement must not sink the headline line
+            if world > 1:
+                raise                                   # ... but on several ranks a lone failure would deadlock the others
+            out[name] = {"error": repr(exc)}
+
     def protocol(engine, n_chains, steps_per_measure, cycles, warm_cycles):
-        for _ in range(warm_cycles):
-            engine.step_all(steps_per_measure)
-            engine.measure()
-        engine.sync()
-        t0 = time.perf_counter()
-        for _ in range(cycles):
-            for _ in range(steps_per_measure):
-                engine.step_all()
-            engine.measure()
-        engine.sync()
-        dt = time.perf_counter() - t0
-        return {"chain_steps_per_s": n_chains * steps_per_measure * cycles / dt,
-                "acceptance_rate": engine.acceptance_rate(), "chains": n_chains,
+        protocols.cycle_protocol(engine, warm_cycles, steps_per_measure, "none", fused=True)
+        dt, _ = protocols.cycle_protocol(engine, cycles, steps_per_measure, "none")
+        dt = reduce_max(dt)
+        return {"chain_steps_per_s": float(n_chains) * world * steps_per_measure * cycles / dt,
+                "acceptance_rate": engine.acceptance_rate(), "chains_per_gpu": n_chains,
                 "protocol": "(%d x step_all + measure) x %d" % (steps_per_measure, cycles)}
 
     a = b = (1.0, 2.0, 4.0, 8.0)
     for dtype in ("f32", "f64"):
-        out["config3" + ("" if dtype == "f32" else "_f64")] = protocol(
+        guarded("config3" + ("" if dtype == "f32" else "_f64"), lambda: protocol(
             me.MetropolisEngine(me.DiagQuadratic(a, b), None, [0.0] * 4, [0j] * 4, temp=1.0, n_chains=n, seed=2026,
-                                dtype=dtype, device=device), n, 10, 100, 60)
+                                dtype=dtype, device=device, chain_offset=rank * n), n, 10, 100, 60))
     m = np.random.default_rng(5).standard_normal((64, 64))
+    amat = m @ m.T / 64 + np.identity(64)
+    n4 = n // 2
     for dtype, kernel, state_bytes in (("f32", "k_step_dense64_bf16x3", 8 * 64 + 16), ("f64", "k_step_dense64_f64", 16 * 64 + 32)):
-        try:
-            e4 = me.MetropolisEngine(me.DenseQuadratic(m @ m.T / 64 + np.identity(64)), None, [0.0] * 64, None, temp=1.0,
-                                     n_chains=n // 2, seed=2026, cov_mode="fixed", dtype=dtype, device=device)
+        suffix = "" if dtype == "f32" else "_f64"
+
+        def identity_shape():
+            e4 = me.MetropolisEngine(me.DenseQuadratic(amat), None, [0.0] * 64, None, temp=1.0, n_chains=n4, seed=2026,
+                                     cov_mode="fixed", dtype=dtype, device=device, chain_offset=rank * n4)
             e4.time_steps(30, 1)
-            ms = e4.time_steps(100, 1) / 100
-            out["config4" + ("" if dtype == "f32" else "_f64")] = {
-                "chain_steps_per_s": (n // 2) / (ms * 1e-3), "ms_per_launch": ms, "chains": n // 2,
-                "state_GBps": state_bytes * (n // 2) / (ms * 1e-3) / 1e9, "kernel": kernel, "dtype": dtype}
-            del e4
-        except Exception as exc:                        # a side measurement must not sink the headline line
-            out["config4" + ("" if dtype == "f32" else "_f64")] = {"error": repr(exc)}
-    # config 4's parameter space with the REFERENCE's semantics (every chain its own adaptive 64 x 64 shape, streamed
-    # kernels): what BASELINE's "identity and pooled_shared" prescription avoids, timed so that its cost is on record
-    try:
-        e4 = me.MetropolisEngine(me.DenseQuadratic(m @ m.T / 64 + np.identity(64)), None, [0.0] * 64, None, temp=1.0,
-                                 n_chains=n // 8, seed=2026, cov_mode="reference", dtype="f32", device=device)
-        for _ in range(52):
-            e4.step_all()
-            e4.measure()
-        out["config4_reference_shapes"] = protocol(e4, n // 8, 10, 5, 0)
-        out["config4_reference_shapes"]["dtype"] = "f32"
-        del e4
-    except Exception as exc:
-        out["config4_reference_shapes"] = {"error": repr(exc)}
+            ms = reduce_max(e4.time_steps(100, 1) / 100)
+            return {"chain_steps_per_s": float(n4) * world / (ms * 1e-3), "ms_per_launch": ms, "chains_per_gpu": n4,
+                    "state_GBps_per_gpu": state_bytes * n4 / (ms * 1e-3) / 1e9, "kernel": kernel, "dtype": dtype}
+
+        def pooled_shape():
+            e4 = me.MetropolisEngine(me.DenseQuadratic(amat), None, [0.0] * 64, None, temp=1.0, n_chains=n4, seed=2026,
+                                     cov_mode="pooled", dtype=dtype, device=device, chain_offset=rank * n4)
+            native_comm(e4)
+            rec = protocols.config4_pooled(e4, n4, world, backend=backend, reduce_max=reduce_max)
+            rec.update(kernel=kernel + "<shared factor>", dtype=dtype, allreduce_backend=backend or "torch.distributed")
+            e4.close()
+            return rec
+
+        guarded("config4" + suffix, identity_shape)
+        guarded("config4_pooled" + suffix, pooled_shape)
+    if world == 1:
+        # config 4's parameter space with the REFERENCE's semantics (every chain its own adaptive 64 x 64 shape, streamed
+        # kernels): what BASELINE's "identity and pooled_shared" prescription avoids, timed so that its cost is on record
+        def reference_shapes():
+            e4 = me.MetropolisEngine(me.DenseQuadratic(amat), None, [0.0] * 64, None, temp=1.0, n_chains=n // 8, seed=2026,
+                                     cov_mode="reference", dtype="f32", device=device)
+            for _ in range(52):
+                e4.step_all()
+                e4.measure()
+            rec = protocol(e4, n // 8, 10, 5, 0)
+            rec["dtype"] = "f32"
+            return rec
+        guarded("config4_reference_shapes", reference_shapes)
     src = os.path.join(ROOT, "examples", "user_energy_cylinder.h")
+    n5 = n // 4
     for dtype in ("f32", "f64"):
-        out["config5" + ("" if dtype == "f32" else "_f64")] = protocol(
-            me.MetropolisEngine(me.UserEnergy("cylinder", src, (1.0, 0.5, 1.0)), me.AbsReal0AtLeast(1.0), [0.1, 0.0],
-                                [0.05] * 7, temp=0.1, n_chains=n // 4, seed=2026, dtype=dtype, device=device),
-            n // 4, 10, 100, 60)
+        def cylinder(use_backend=backend):
+            e5 = me.MetropolisEngine(me.UserEnergy("cylinder", src, (1.0, 0.5, 1.0)), me.AbsReal0AtLeast(1.0), [0.1, 0.0],
+                                     [0.05] * 7, temp=0.1, n_chains=n5, seed=2026, dtype=dtype, device=device,
+                                     chain_offset=rank * n5)
+            if use_backend == "rccl-native":
+                native_comm(e5)
+            rec = protocols.config5(e5, n5, world, cycles=200, backend=use_backend, reduce_max=reduce_max)
+            rec.update(dtype=dtype, allreduce_backend=use_backend or "torch.distributed")
+            e5.close()
+            return rec
+        guarded("config5" + ("" if dtype == "f32" else "_f64"), cylinder)
+        if backend == "rccl-native" and dtype == "f32":
+            guarded("config5_torch_allreduce", lambda: cylinder(None))     # the same cycle through torch.distributed
     return out
 
 
@@ -243,7 +273,9 @@ def main():
     ap.add_argument("--hbm-chains-log2", type=int, default=22, help="chains of the cache-free roofline_hbm run (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length (0 = skip)")
     ap.add_argument("--extras", type=int, default=1, help="1: also time the float32 build of the headline kernel and "
-                    "BASELINE configs 3-5 (informational, a few seconds; configs 3-5 on a single GPU only)")
+                    "BASELINE configs 3-5 through their protocols (a few seconds; at every --gpus N)")
+    ap.add_argument("--pool-backend", default="native", choices=("native", "torch"),
+                    help="all-reduce of the pooled moments: the engine's own RCCL communicator, or torch.distributed")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -267,7 +299,7 @@ def main():
     import torch
     import torch.distributed as dist
     import metropolisengine_amd as me
-    from metropolisengine_amd.distributed import pooled_statistics
+    from metropolisengine_amd.distributed import init_native_comm, pooled_statistics
 
     # Rehearsal on a one-GPU box (never used by the driver): METROPOLIS_BENCH_REHEARSAL=1 puts every rank on GPU 0 and
     # uses gloo for the barrier / timing reduction / pooled moments, so the multi-rank code path can be exercised there.
@@ -287,6 +319,13 @@ def main():
     comm_device = "cpu" if (rehearsal or not distributed) else "cuda"
 
     n_local = 1 << args.chains_log2
+    # rehearsal ranks share GPU 0: RCCL refuses two ranks on one device, the gloo group carries the moments there
+    pool_backend = "rccl-native" if (args.pool_backend == "native" and not rehearsal) else None
+
+    def native_comm(eng):
+        """Give ``eng`` its RCCL communicator over all ranks (unique id broadcast through the process group)."""
+        if pool_backend == "rccl-native":
+            init_native_comm(eng, world_size=world)
 
     def make_engine(dtype, chains_log2=args.chains_log2, **extra):
         n = 1 << chains_log2
@@ -352,8 +391,13 @@ def main():
             # float64 vector instructions take at least 4 cycles like the float32 ones the helper assumes; most take more
             fused["valu_issue"] = issue_utilisation(torch, local_rank, fused["value"], "_f64" if args.dtype == "f64" else "")
 
-    stats = pooled_statistics(engine)                      # the one collective: RCCL all-reduce of pooled moments
+    # the one collective: the all-reduce of the pooled moments -- through the engine's own RCCL communicator
+    # (me_comm_init_rank + me_pooled_moments_allreduce, no PyTorch in the data path) unless --pool-backend torch
+    native_comm(engine)
+    stats = pooled_statistics(engine, backend=pool_backend)
+    rccl_version = engine.comm_info()[2] if pool_backend == "rccl-native" else None
     engine.sync()
+    engine.close()
     del engine
 
     # the cache-free figure: same kernel, state beyond the 256 MiB Infinity Cache (identity shape, no covariance fields)
@@ -390,8 +434,14 @@ def main():
         del e32
 
     extras = None
-    if world == 1 and args.extras:
-        extras = other_configs(me, local_rank, args.chains_log2)
+    if args.extras:
+        def reduce_max(value):
+            if not distributed:
+                return value
+            t = torch.tensor([value], dtype=torch.float64, device=comm_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t[0])
+        extras = other_configs(me, rank, world, local_rank, args.chains_log2, reduce_max, pool_backend, native_comm)
 
     if rank == 0:
         line = {
@@ -414,7 +464,9 @@ def main():
             "fused": fused,
             "other_configs": extras,
             "multi_gpu": {"backend": backend, "ranks_seen_by_allreduce": ranks_seen, "chain_offsets": offsets,
-                          "pooled_chains": stats["n_chains"]},
+                          "pooled_chains": stats["n_chains"],
+                          "pooled_moments_backend": pool_backend or "torch.distributed", "rccl_version": rccl_version,
+                          "ranks_seen_by_pooled_allreduce": int(round(stats["n_chains"] / float(n_local)))},
             "acceptance_rate": stats["acceptance_rate"],
             "pooled_variance_mean": float(sum(stats["covariance"][i][i] for i in range(N_REAL)) / N_REAL),
         }

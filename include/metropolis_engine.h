@@ -14,7 +14,8 @@
  *   me_get / me_set      <- attribute reads/writes (real_params, real_mean, covariance_matrix_real, ...)
  *                           README.md:49-51; also the only "checkpoint" the reference has (ctor warm start, :17)
  *   me_accept_stats      <- the bool returned by step_all (:259), accumulated
- *   me_pooled_moments*   <- no reference equivalent (ensemble estimate across chains; the one collective)
+ *   me_pooled_moments*   <- no reference equivalent (ensemble estimate across chains)
+ *   me_comm_*, me_pooled_moments_allreduce*  <- no reference equivalent (the one collective: RCCL all-reduce of the moments)
  *   me_last_error        <- Python exceptions (:39 ValueError, :92/:438 AssertionError, numpy ValueError :270)
  *
  * Conventions: plain pointers and sizes only; every function returns an me_status (0 = ok); the library owns
@@ -205,6 +206,29 @@ int me_pooled_moments_device(me_engine *engine, void *device_out, int64_t n_doub
  * reduction may be in flight per engine (ME_ERR_STATE otherwise). */
 int me_pooled_moments_begin(me_engine *engine);
 int me_pooled_moments_end(me_engine *engine, double *host_out, int64_t n_doubles);
+/* RCCL behind the C ABI: the ONE collective of the engine, a sum all-reduce (fp64) of the pooled-moment vector over the
+ * ranks of a multi-GPU job (one process and one engine per GPU; chains shard with no other exchange).  No reference
+ * counterpart (the reference runs one chain in one process; BASELINE.json: "RCCL all-reduce only for the pooled
+ * covariance/observables").  librccl is loaded on first use; ME_ERR_UNSUPPORTED when it cannot be.
+ *   me_comm_unique_id   rank 0: ncclGetUniqueId into a caller buffer of ME_COMM_ID_BYTES, to be handed to every rank by
+ *                       whatever channel the host program has (MPI, a file, torch.distributed, a socket)
+ *   me_comm_init_rank   every rank: ncclCommInitRank on the engine's device (collective: returns when all have joined)
+ *   me_comm_destroy     ncclCommDestroy (me_destroy does it too)
+ *   me_comm_info        rank / world of the communicator (-1 / 0 without one) and the RCCL version code
+ *   me_pooled_moments_allreduce        k_pool_reduce -> k_pool_finish on the engine's stream, then on the engine's second
+ *                       stream behind an event: ncclAllReduce(sum, fp64, in place) -> copy to pinned host memory; waits for
+ *                       that copy and hands out the moments of ALL ranks' chains (same layout as me_pooled_moments: n,
+ *                       accepted and proposed are global too)
+ *   me_pooled_moments_allreduce_begin  the same without waiting: collect with me_pooled_moments_end.  The engine's main
+ *                       stream never waits for another rank and the host never synchronises inside a cycle
+ * Every rank must call the all-reduce forms the same number of times, in the same order. */
+#define ME_COMM_ID_BYTES 128
+int me_comm_unique_id(void *id_out, size_t bytes);
+int me_comm_init_rank(me_engine *engine, const void *unique_id, size_t bytes, int32_t rank, int32_t world);
+int me_comm_destroy(me_engine *engine);
+int me_comm_info(me_engine *engine, int32_t *rank, int32_t *world, int32_t *rccl_version);
+int me_pooled_moments_allreduce(me_engine *engine, double *host_out, int64_t n_doubles);
+int me_pooled_moments_allreduce_begin(me_engine *engine);
 /* Install the shared proposal factor of ME_COV_POOLED: packed like ME_FIELD_FACTOR, [P] doubles. */
 int me_set_shared_factor(me_engine *engine, const double *packed_factor, int64_t n_doubles);
 /* Tuning knob (process-wide, default 224 MiB): launches whose working set exceeds this many bytes access their read-once

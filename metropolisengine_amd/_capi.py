@@ -18,6 +18,7 @@ FLAG_REFERENCE_ENERGY_LEDGERS = 2
 REJECT_NONE, REJECT_ABS_REAL0_GE, REJECT_USER = 0, 1, 2
 STEP_ALL, STEP_REAL_GROUP, STEP_COMPLEX_GROUP, STEP_COMPLEX_MAGNITUDE_PHASE = range(4)
 COV_REFERENCE, COV_FIXED, COV_POOLED = 0, 1, 2
+COMM_ID_BYTES = 128
 (FIELD_PARAMS, FIELD_ENERGY, FIELD_WIDTH, FIELD_MEAN, FIELD_COV, FIELD_OBS_MEAN, FIELD_FACTOR, FIELD_ENERGY_TOTAL) = range(8)
 
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -68,6 +69,13 @@ SYMBOLS = {
     "me_pooled_moments_size": (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int64)]),
     "me_pooled_moments": (ctypes.c_int, [_H, _dp, ctypes.c_int64]),
     "me_pooled_moments_device": (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.c_int64]),
+    "me_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
+    "me_comm_init_rank": (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32]),
+    "me_comm_destroy": (ctypes.c_int, [_H]),
+    "me_comm_info": (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+                                    ctypes.POINTER(ctypes.c_int32)]),
+    "me_pooled_moments_allreduce": (ctypes.c_int, [_H, _dp, ctypes.c_int64]),
+    "me_pooled_moments_allreduce_begin": (ctypes.c_int, [_H]),
     "me_set_shared_factor": (ctypes.c_int, [_H, _dp, ctypes.c_int64]),
     "me_get_shared_factor": (ctypes.c_int, [_H, _dp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32)]),
     "me_set_accept_stats": (ctypes.c_int, [_H, ctypes.c_uint64, ctypes.c_uint64]),

@@ -11,6 +11,7 @@
 #include <atomic>
 #include <vector>
 
+#include "me_comm.h"
 #include "me_internal.h"
 
 namespace me {
@@ -113,6 +114,21 @@ static bool host_factor(std::vector<double> &m, int nr, int nc) {
   return true;
 }
 
+// whether the caller's initial proposal matrices (me_config.covariance_real / _complex) are the identity (:63-70)
+static bool initial_shape_is_identity(const me_config *c) {
+  if (c->covariance_real)
+    for (int i = 0; i < c->n_real; ++i)
+      for (int j = 0; j <= i; ++j)
+        if (c->covariance_real[i * c->n_real + j] != (i == j ? 1.0 : 0.0)) return false;
+  if (c->covariance_complex)
+    for (int i = 0; i < c->n_complex; ++i)
+      for (int j = 0; j <= i; ++j) {
+        const double re = c->covariance_complex[2 * (i * c->n_complex + j)], im = c->covariance_complex[2 * (i * c->n_complex + j) + 1];
+        if (re != (i == j ? 1.0 : 0.0) || (i != j && im != 0.0)) return false;
+      }
+  return true;
+}
+
 }  // namespace me
 
 using namespace me;
@@ -153,6 +169,10 @@ struct me_engine {
   hipStream_t copy_stream = nullptr;
   hipEvent_t pool_reduced = nullptr, pool_copied = nullptr;
   bool pool_pending = false;
+  // RCCL communicator of this engine's rank (me_comm_init_rank); null = single-GPU engine
+  const RcclApi *rccl = nullptr;
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
   // time-series trace of a few chains (the reference's per-measure appends, :350-356)
   double *trace_dev = nullptr;
   long long trace_chains = 0, trace_stride = 1, trace_rows = 0, trace_capacity = 0;
@@ -339,6 +359,7 @@ void release(me_engine *e) {
                   e->coef_dev, e->row_dev, e->accept_slots, e->accept_total, e->status, e->pool_dev, e->pool_partials, e->trace_dev};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
+  if (e->comm && e->rccl) (void)e->rccl->comm_destroy(e->comm);
   if (e->pool_copied) (void)hipEventDestroy(e->pool_copied);
   if (e->pool_reduced) (void)hipEventDestroy(e->pool_reduced);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
@@ -423,10 +444,17 @@ int me_create(const me_config *c, me_engine **out) {
                   "parameter spaces beyond " + std::to_string(kMaxRegisterDof) + " real degrees of freedom run with the "
                   "identity proposal shape (ME_COV_FIXED, cov_mode=\"fixed\") or, pure real spaces, one shared factor "
                   "(ME_COV_POOLED); per-chain shapes are not available there");
+    // an initial covariance that is not the identity makes the engine start with a SHARED factor (cov_kind below), which the
+    // runtime set has for pure real spaces only and which doubles the LDS a block needs
+    const bool starts_shared = !initial_shape_is_identity(c);
+    if (starts_shared && c->n_complex > 0)
+      return fail(nullptr, ME_ERR_UNSUPPORTED,
+                  "parameter spaces beyond " + std::to_string(kMaxRegisterDof) + " real degrees of freedom with complex "
+                  "parameters run with the identity proposal shape only: leave covariance_matrix_real / _complex unset");
     {
       // a dense energy needs all of x' at once, a shared factor all of g: both are parked in LDS, 64 lanes x D values each
       const long long per_block = (long long)(c->n_real + 2 * c->n_complex) * 64 * (c->dtype == ME_F32 ? 4 : 8);
-      const bool dense = c->energy_kind == ME_ENERGY_DENSE_QUAD, pooled = c->cov_mode == ME_COV_POOLED;
+      const bool dense = c->energy_kind == ME_ENERGY_DENSE_QUAD, pooled = c->cov_mode == ME_COV_POOLED || starts_shared;
       if ((dense || pooled) && per_block * (pooled ? 2 : 1) > 150 * 1024)
         return fail(nullptr, ME_ERR_UNSUPPORTED,
                     "a dense quadratic form or a shared proposal factor beyond " + std::to_string(kMaxRegisterDof) +
@@ -1067,9 +1095,15 @@ int me_pooled_moments(me_engine *e, double *host_out, int64_t n_doubles) {
   return ME_OK;
 }
 
-int me_pooled_moments_begin(me_engine *e) {
-  if (!e) return ME_ERR_INVALID;
+namespace {
+// The split reduction: the two reduction kernels behind the work already queued on the engine's stream; then, on the
+// engine's SECOND stream behind an event, (all-reduce over the ranks of the engine's communicator,) the copy into the
+// pinned staging buffer and the event me_pooled_moments_end waits for.  Nothing here waits on the host, and the engine's
+// main stream never waits for another rank: steps enqueued afterwards run beside the collective.
+int begin_pooled(me_engine *e, bool allreduce) {
   if (e->pool_pending) return fail(e, ME_ERR_STATE, "a pooled-moment reduction is already in flight: call me_pooled_moments_end first");
+  if (allreduce && !e->comm)
+    return fail(e, ME_ERR_STATE, "this engine has no communicator: call me_comm_init_rank first (single-GPU engines use me_pooled_moments)");
   ME_HIP(e, hipSetDevice(e->device));
   if (!e->copy_stream) {
     ME_HIP(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
@@ -1081,9 +1115,92 @@ int me_pooled_moments_begin(me_engine *e) {
   if (rc != ME_OK) return rc;
   ME_HIP(e, hipEventRecord(e->pool_reduced, e->stream));
   ME_HIP(e, hipStreamWaitEvent(e->copy_stream, e->pool_reduced, 0));
+  if (allreduce) {
+    const ncclResult_t nrc = e->rccl->all_reduce(e->pool_dev, e->pool_dev, (size_t)n_doubles, ncclDouble, ncclSum, e->comm, e->copy_stream);
+    if (nrc != ncclSuccess) return fail(e, ME_ERR_HIP, std::string("ncclAllReduce: ") + e->rccl->error_string(nrc));
+  }
   ME_HIP(e, hipMemcpyAsync(e->pool_host, e->pool_dev, sizeof(double) * (size_t)n_doubles, hipMemcpyDeviceToHost, e->copy_stream));
   ME_HIP(e, hipEventRecord(e->pool_copied, e->copy_stream));
   e->pool_pending = true;
+  return ME_OK;
+}
+}  // namespace
+
+int me_pooled_moments_begin(me_engine *e) {
+  if (!e) return ME_ERR_INVALID;
+  return begin_pooled(e, false);
+}
+
+int me_pooled_moments_allreduce_begin(me_engine *e) {
+  if (!e) return ME_ERR_INVALID;
+  return begin_pooled(e, true);
+}
+
+int me_pooled_moments_allreduce(me_engine *e, double *host_out, int64_t n_doubles) {
+  if (!e || !host_out) return ME_ERR_INVALID;
+  if (n_doubles != moments_size(e->nr, e->nc)) return fail(e, ME_ERR_INVALID, "wrong pooled-moment buffer length");
+  const int rc = begin_pooled(e, true);
+  return rc != ME_OK ? rc : me_pooled_moments_end(e, host_out, n_doubles);
+}
+
+int me_comm_unique_id(void *id_out, size_t bytes) {
+  if (!id_out || bytes != ME_COMM_ID_BYTES) return fail(nullptr, ME_ERR_INVALID, "the unique id is ME_COMM_ID_BYTES bytes");
+  static_assert(sizeof(ncclUniqueId) == ME_COMM_ID_BYTES, "ME_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+  std::string err;
+  const RcclApi *api = rccl_api(&err);
+  if (!api) return fail(nullptr, ME_ERR_UNSUPPORTED, err);
+  ncclUniqueId id;
+  const ncclResult_t nrc = api->get_unique_id(&id);
+  if (nrc != ncclSuccess) return fail(nullptr, ME_ERR_HIP, std::string("ncclGetUniqueId: ") + api->error_string(nrc));
+  std::memcpy(id_out, &id, sizeof(id));
+  return ME_OK;
+}
+
+int me_comm_init_rank(me_engine *e, const void *unique_id, size_t bytes, int32_t rank, int32_t world) {
+  if (!e || !unique_id) return ME_ERR_INVALID;
+  if (bytes != ME_COMM_ID_BYTES) return fail(e, ME_ERR_INVALID, "the unique id is ME_COMM_ID_BYTES bytes");
+  if (world < 1 || rank < 0 || rank >= world) return fail(e, ME_ERR_INVALID, "rank out of range");
+  if (e->comm) return fail(e, ME_ERR_STATE, "this engine already has a communicator (me_comm_destroy first)");
+  if (e->pool_pending) return fail(e, ME_ERR_STATE, "a pooled-moment reduction is in flight");
+  std::string err;
+  const RcclApi *api = rccl_api(&err);
+  if (!api) return fail(e, ME_ERR_UNSUPPORTED, err);
+  ME_HIP(e, hipSetDevice(e->device));       // the communicator binds to the current device: one engine, one GPU, one rank
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id, sizeof(id));
+  ncclComm_t comm = nullptr;
+  const ncclResult_t nrc = api->comm_init_rank(&comm, world, id, rank);   // collective: returns once every rank has joined
+  if (nrc != ncclSuccess) return fail(e, ME_ERR_HIP, std::string("ncclCommInitRank: ") + api->error_string(nrc));
+  e->rccl = api;
+  e->comm = comm;
+  e->comm_rank = rank;
+  e->comm_world = world;
+  return ME_OK;
+}
+
+int me_comm_destroy(me_engine *e) {
+  if (!e) return ME_ERR_INVALID;
+  if (!e->comm) return ME_OK;
+  if (e->pool_pending) return fail(e, ME_ERR_STATE, "a pooled-moment reduction is in flight (me_pooled_moments_end first)");
+  ME_HIP(e, hipSetDevice(e->device));
+  if (e->copy_stream) ME_HIP(e, hipStreamSynchronize(e->copy_stream));
+  const ncclResult_t nrc = e->rccl->comm_destroy(e->comm);
+  e->comm = nullptr;
+  e->comm_rank = 0;
+  e->comm_world = 1;
+  if (nrc != ncclSuccess) return fail(e, ME_ERR_HIP, std::string("ncclCommDestroy: ") + e->rccl->error_string(nrc));
+  return ME_OK;
+}
+
+int me_comm_info(me_engine *e, int32_t *rank, int32_t *world, int32_t *rccl_version) {
+  if (!e) return ME_ERR_INVALID;
+  if (rank) *rank = e->comm ? e->comm_rank : -1;
+  if (world) *world = e->comm ? e->comm_world : 0;
+  if (rccl_version) {
+    int v = 0;
+    if (e->rccl) (void)e->rccl->get_version(&v);
+    *rccl_version = v;
+  }
   return ME_OK;
 }
 

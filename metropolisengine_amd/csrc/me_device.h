@@ -533,6 +533,15 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F &&fn) {
   static_for_impl(fn, std::make_integer_sequence<int, N>{});
 }
+// A 64-bit address put back together from two 32-bit halves that went through v_readfirstlane (which returns int).  Both
+// halves are ZERO-extended: the first version or-ed the low half in as a (signed) int, so a tile base whose low half had
+// bit 31 set sign-extended into the high half -- a wild pointer in the streamed-factor descriptor, the asynchronous GPU
+// fault that aborted test_64_real_per_chain_shapes_follow_the_oracle on Oct 4 (gpurun_out/streamed.log; fixed in dad04c0).
+__host__ __device__ constexpr unsigned long long join_halves(int hi, int lo) {
+  return ((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo;
+}
+static_assert(join_halves(0x00007f12, (int)0x80000000u) == 0x00007f1280000000ull, "low half with bit 31 set must not sign-extend");
+static_assert(join_halves((int)0xffff8000u, (int)0xfffffff0u) == 0xffff8000fffffff0ull, "both halves are zero-extended");
 // bytes of one chunk of the streamed factor per lane (two chunks live in registers)
 #ifndef ME_STREAM_CHUNK_BYTES
 #define ME_STREAM_CHUNK_BYTES 128
@@ -676,9 +685,8 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
         constexpr int CH = (int)(ME_STREAM_CHUNK_BYTES / sizeof(R));
         const R *tile_base = a.factor + (c >> 6) * (long long)PF * 64;
         const unsigned long long tb = (unsigned long long)tile_base;
-        // (readfirstlane returns int: through unsigned, or a low half with bit 31 set sign-extends into the high half)
-        const R *tile_uniform = (const R *)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(tb >> 32)) << 32) |
-                                            (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)tb));
+        const R *tile_uniform = (const R *)join_halves(__builtin_amdgcn_readfirstlane((int)(tb >> 32)),
+                                                       __builtin_amdgcn_readfirstlane((int)(unsigned int)tb));
         const __amdgpu_buffer_rsrc_t tile = __builtin_amdgcn_make_buffer_rsrc(const_cast<R *>(tile_uniform), 0,
                                                                                (unsigned int)(PF * 64 * sizeof(R)), 0x00020000);
         const unsigned int lane_off = (unsigned int)(c & 63) * (unsigned int)sizeof(R);

@@ -49,9 +49,13 @@ struct RuntimeStep {
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// Safe by construction: `weights` is non-null for ME_ENERGY_DIAG_QUAD only (fill() below), every other kind gets `iso`
+// (0 for the dense form, whose energy never comes through here).  Round 2's last GPU call core-dumped in an experiment
+// build that compiled the dense branch of k_step_runtime_lds out: the kernel then fell through to this function with
+// energy_kind = ME_ENERGY_DENSE_QUAD and dereferenced the null `weights` (tools/README.md, "the rt_noenergy fault").
 template <typename R>
 __device__ __forceinline__ R weight_of(const RuntimeStep<R> &p, int d) {
-  return p.energy_kind == ME_ENERGY_ISO_QUAD ? p.iso : p.weights[d];
+  return p.weights ? p.weights[d] : p.iso;
 }
 
 template <typename R>
@@ -331,6 +335,17 @@ __device__ __forceinline__ void tri_rows_mfma(const R *__restrict__ tri_packed, 
   }
 }
 
+// LDS is the exchange medium between the lanes of ONE wavefront here (lane l parks column l, the matrix-core operands
+// are read across columns, tri_rows_mfma's callback writes other lanes' columns): every such hand-over is fenced with
+// __builtin_amdgcn_wave_barrier() + an LDS fence (lds_handover) so that it does not rest on the compiler being unable to
+// reorder the accesses.
+static_assert(kStepThreads == 64, "k_step_runtime_lds: one wavefront per block (cross-lane LDS traffic is fenced per wavefront)");
+__device__ __forceinline__ void lds_handover() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <typename R, bool SHARED>
 __global__ void __launch_bounds__(kStepThreads) k_step_runtime_lds(StepArgs<R> a, RuntimeStep<R> p, const R *__restrict__ folded) {
   using N_ = Num<R>;
@@ -398,6 +413,7 @@ __global__ void __launch_bounds__(kStepThreads) k_step_runtime_lds(StepArgs<R> a
           }
         }
       }
+      lds_handover();                                       // x (and g) are parked: other lanes read them as MFMA operands
       if constexpr (SHARED) {
         // x' = x + w L g, row by row; L packed lower triangle (pure real spaces: nc == 0)
         if (ME_RUNTIME_MFMA) {
@@ -411,6 +427,7 @@ __global__ void __launch_bounds__(kStepThreads) k_step_runtime_lds(StepArgs<R> a
         } else {
           tri_rows_blocked(a.factor, gs, D, lane, [&](int i, R acc, R) { xp[i][lane] = fma_(s_r, acc, xp[i][lane]); });
         }
+        lds_handover();                                     // x' was written across lanes: visible before anyone reads it
       }
       // ---- energy of the proposal
       R e_new = R(0);
@@ -450,6 +467,7 @@ __global__ void __launch_bounds__(kStepThreads) k_step_runtime_lds(StepArgs<R> a
       else if (p.group == GROUP_REAL) w_r = w;
       else w_c = w;
       wave_accepted += (unsigned int)__popcll(__ballot(accept));
+      lds_handover();                                       // the next sweep re-parks x over what the energy product read
     }
     bad_width |= valid && !(w > R(0));
     if (valid) {

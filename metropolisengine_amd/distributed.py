@@ -69,12 +69,61 @@ def moments_to_statistics(moments, n_real, n_complex):
             "acceptance_rate": accepted / proposed if proposed else float("nan")}
 
 
-def pooled_statistics(engine, group=None):
-    """Ensemble mean / covariance / observables over ALL ranks' chains of ``engine`` (one all-reduce)."""
-    import torch
-    import torch.distributed as dist
+def init_native_comm(engine, rank=None, world_size=None, group=None, id_file=None):
+    """Give ``engine`` its own RCCL communicator (``me_comm_init_rank``; backend ``"rccl-native"``): rank 0 draws the
+    unique id (``me_comm_unique_id``) and hands it to the other ranks -- through the initialised ``torch.distributed``
+    process group (any backend: a 128-byte broadcast, the only thing PyTorch is used for), or, with ``id_file``, through a
+    file on a file system all ranks see (rank 0 writes ``id_file`` atomically, the others poll for it; no PyTorch at
+    all).  Collective over all ranks; afterwards ``pooled_statistics(engine, backend="rccl-native")`` and the
+    ``_begin`` / ``_end`` pair run the all-reduce on the engine's own HIP streams."""
+    import os
+    import time
+    if id_file is not None:
+        if rank is None or world_size is None:
+            raise ValueError("id_file needs explicit rank and world_size")
+        if rank == 0:
+            uid = engine.comm_unique_id()
+            tmp = "%s.tmp.%d" % (id_file, os.getpid())
+            with open(tmp, "wb") as fh:
+                fh.write(uid)
+            os.replace(tmp, id_file)
+        else:
+            deadline = time.time() + 300.0
+            while not os.path.exists(id_file):
+                if time.time() > deadline:
+                    raise TimeoutError("no unique id appeared at %s" % id_file)
+                time.sleep(0.01)
+            with open(id_file, "rb") as fh:
+                uid = fh.read()
+    else:
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            if (world_size or 1) != 1:
+                raise RuntimeError("init_native_comm: no process group to broadcast the unique id through (pass id_file)")
+            rank, world_size, uid = 0, 1, engine.comm_unique_id()
+        else:
+            rank, world_size = dist.get_rank(group), dist.get_world_size(group)
+            uid = engine.comm_unique_id() if rank == 0 else bytes(128)
+            dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+            t = torch.tensor(list(uid), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            uid = bytes(t.cpu().tolist())
+    engine.comm_init(uid, rank, world_size)
+    return rank, world_size
+
+
+def pooled_statistics(engine, group=None, backend=None):
+    """Ensemble mean / covariance / observables over ALL ranks' chains of ``engine`` (one all-reduce).
+
+    ``backend="rccl-native"``: the engine's own communicator (:func:`init_native_comm`); default: ``torch.distributed``
+    (RCCL through the ``nccl`` backend, or ``gloo`` on CPU), the identity without a process group."""
     nr, nc = engine.num_real_params, engine.num_complex_params
     size = moments_size(nr, nc)
+    if backend == "rccl-native":
+        return moments_to_statistics(engine.pooled_moments_allreduce(), nr, nc)
+    import torch
+    import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl":
         # The buffer must live on the ENGINE's GPU (the engine's own stream writes it) and that must be the device the
         # process group communicates from: a mismatch would be a cross-device write, not an error message.
@@ -96,17 +145,24 @@ def pooled_statistics(engine, group=None):
     return moments_to_statistics(total, nr, nc)
 
 
-def pooled_statistics_begin(engine):
+def pooled_statistics_begin(engine, backend=None):
     """Start the pooled reduction of the engine's current state without stalling its stream (see
-    ``me_pooled_moments_begin``); keep enqueuing steps, then call :func:`pooled_statistics_end`."""
-    engine.pooled_moments_begin()
+    ``me_pooled_moments_begin``); keep enqueuing steps, then call :func:`pooled_statistics_end` with the same backend.
+    With ``backend="rccl-native"`` the all-reduce itself is enqueued too (``me_pooled_moments_allreduce_begin``): nothing
+    between ``_begin`` and ``_end`` touches the host."""
+    if backend == "rccl-native":
+        engine.pooled_moments_allreduce_begin()
+    else:
+        engine.pooled_moments_begin()
 
 
-def pooled_statistics_end(engine, group=None):
-    """Collect the reduction started by :func:`pooled_statistics_begin`, all-reduce it over the ranks and convert it.
-    The GPU keeps executing whatever was enqueued in between, so the copy, the all-reduce and the host arithmetic
-    are off the sampler's critical path."""
-    total = allreduce_moments(engine.pooled_moments_end(), group)
+def pooled_statistics_end(engine, group=None, backend=None):
+    """Collect the reduction started by :func:`pooled_statistics_begin`, all-reduce it over the ranks (already done on
+    the device with ``backend="rccl-native"``) and convert it.  The GPU keeps executing whatever was enqueued in
+    between, so the copy, the all-reduce and the host arithmetic are off the sampler's critical path."""
+    total = engine.pooled_moments_end()
+    if backend != "rccl-native":
+        total = allreduce_moments(total, group)
     return moments_to_statistics(total, engine.num_real_params, engine.num_complex_params)
 
 
@@ -135,11 +191,11 @@ def pooled_factor(covariance, n_real, n_complex, jitter=0.0):
     return np.asarray(packed, dtype=np.float64)
 
 
-def adapt_pooled_shape(engine, group=None, jitter=0.0):
+def adapt_pooled_shape(engine, group=None, jitter=0.0, backend=None):
     """The many-chain counterpart of the reference's per-chain covariance adaptation (metropolis_engine.py:416-427 feeding
     :261-302): pool the ensemble covariance over all ranks (one all-reduce), factor it and install it as the proposal
     shape every chain shares (``cov_mode="pooled"``).  Returns the pooled statistics."""
-    stats = pooled_statistics(engine, group)
+    stats = pooled_statistics(engine, group, backend=backend)
     engine.set_shared_factor(pooled_factor(stats["covariance"], engine.num_real_params, engine.num_complex_params,
                                            jitter=jitter))
     return stats

@@ -437,6 +437,43 @@ class MetropolisEngine:
         self._check(self._lib.me_pooled_moments_end(self._handle, _as_double_ptr(out), size.value))
         return out
 
+    # -- RCCL behind the C ABI (me_comm_*): the all-reduce of the moments runs on the engine's own streams, no PyTorch
+    @staticmethod
+    def comm_unique_id():
+        """Rank 0: a fresh ``ncclUniqueId`` (bytes) to hand to every rank's :meth:`comm_init`."""
+        buf = ctypes.create_string_buffer(_capi.COMM_ID_BYTES)
+        _capi.check(_capi.load().me_comm_unique_id(buf, _capi.COMM_ID_BYTES))
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        """Join the RCCL communicator named by ``unique_id`` as ``rank`` of ``world`` (collective over all ranks)."""
+        uid = bytes(unique_id)
+        if len(uid) != _capi.COMM_ID_BYTES:
+            raise ValueError("the unique id is %d bytes" % _capi.COMM_ID_BYTES)
+        self._check(self._lib.me_comm_init_rank(self._handle, uid, len(uid), int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._check(self._lib.me_comm_destroy(self._handle))
+
+    def comm_info(self):
+        """(rank, world, RCCL version code); (-1, 0, 0) without a communicator."""
+        rank, world, version = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        self._check(self._lib.me_comm_info(self._handle, ctypes.byref(rank), ctypes.byref(world), ctypes.byref(version)))
+        return rank.value, world.value, version.value
+
+    def pooled_moments_allreduce(self):
+        """Ensemble sums over ALL ranks' chains: reduction kernels, ``ncclAllReduce`` and the copy to the host enqueued on
+        the engine's streams; waits for the copy only."""
+        size = ctypes.c_int64()
+        self._check(self._lib.me_pooled_moments_size(self._handle, ctypes.byref(size)))
+        out = np.empty(size.value, dtype=np.float64)
+        self._check(self._lib.me_pooled_moments_allreduce(self._handle, _as_double_ptr(out), size.value))
+        return out
+
+    def pooled_moments_allreduce_begin(self):
+        """The same without waiting; collect with :meth:`pooled_moments_end`."""
+        self._check(self._lib.me_pooled_moments_allreduce_begin(self._handle))
+
     def pooled_moments_into(self, device_ptr, n_doubles):
         """Write the local ensemble sums into caller-owned device memory (e.g. a torch CUDA tensor's data_ptr)."""
         self._check(self._lib.me_pooled_moments_device(self._handle, ctypes.c_void_p(device_ptr), int(n_doubles)))

@@ -125,6 +125,26 @@ class _OracleEngine:
     def set_shared_factor(self, packed):
         self.shared_factor = np.array(packed, dtype=np.float64)
 
+    # the stepping surface metropolisengine_amd.protocols drives (the bench's config 4 / config 5 loops)
+    def step_all(self, n_sweeps=1):
+        self.shard.step(n_sweeps)
+
+    def measure(self):
+        self.shard.measure()
+
+    def sync(self):
+        pass
+
+    def acceptance_rate(self):
+        return self.shard.accepted / self.shard.proposed
+
+    def time_steps(self, n_launches, n_sweeps=1):
+        import time
+        t0 = time.perf_counter()
+        for _ in range(n_launches):
+            self.shard.step(n_sweeps)
+        return (time.perf_counter() - t0) * 1e3
+
 
 def _worker_surface(rank, world, port, n_total, out_dir):
     sys.path.insert(0, ROOT)
@@ -183,3 +203,58 @@ def test_rccl_path_refuses_a_device_mismatch(monkeypatch):
             raise AssertionError("must not be reached")
     with pytest.raises(RuntimeError, match="current device"):
         distributed.pooled_statistics(_Engine())
+
+
+def _worker_protocols(rank, world, port, n_local, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from metropolisengine_amd import protocols
+    from oracle import energies
+    from oracle.manychain import ManyChainOracle
+
+    def reduce_max(value):
+        t = torch.tensor([value], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    # config 5's protocol (2 real + 7 complex, cylinder surrogate + wall), n_local chains per rank, weak scaling
+    shard = ManyChainOracle(2, 7, energies.cylinder_surrogate(2, 7, 1.0, 0.5, 1.0), n_local, seed=2026, temp=0.1,
+                            initial_real_params=[0.1, 0.0], initial_complex_params=[0.05] * 7, chain_offset=rank * n_local,
+                            reject=energies.wall_reject(1.0))
+    eng = _OracleEngine(shard, 2, 7)
+    seen = []
+    dt, last = protocols.cycle_protocol(eng, 3, 2, "sync", on_stats=lambda c, st: seen.append((c, st["n_chains"])))
+    assert [c for c, _ in seen] == [0, 1, 2] and all(n == world * n_local for _, n in seen)
+    seen_overlap = []
+    protocols.cycle_protocol(eng, 3, 2, "overlap", on_stats=lambda c, st: seen_overlap.append((c, st["n_chains"])))
+    assert [c for c, _ in seen_overlap] == [0, 1, 2] and all(n == world * n_local for _, n in seen_overlap)
+    rec5 = protocols.config5(eng, n_local, world, cycles=3, steps_per_measure=2, warm_cycles=1, reduce_max=reduce_max)
+    # config 4's pooled protocol (small stand-in: 3 real parameters, dense form)
+    amat = np.array([[2.0, 0.3, 0.0], [0.3, 1.0, 0.2], [0.0, 0.2, 0.5]])
+    shard4 = ManyChainOracle(3, 0, energies.dense_quadratic(3, 0, amat), n_local, seed=2026, temp=1.0,
+                             initial_real_params=[0.0] * 3, chain_offset=rank * n_local, sampling_width=0.5)
+    eng4 = _OracleEngine(shard4, 3, 0)
+    rec4 = protocols.config4_pooled(eng4, n_local, world, warm_steps=40, steps=5, reduce_max=reduce_max)
+    np.savez(os.path.join(out_dir, "protocols%d.npz" % rank), factor=eng4.shared_factor, x4=shard4.x,
+             ranks5=rec5["ranks_seen_by_allreduce"], pooled5=rec5["pooled_chains"], rate5=rec5["chain_steps_per_s"],
+             us5=rec5["allreduce_us_per_cycle"], ranks4=rec4["ranks_seen_by_allreduce"], pooled4=rec4["pooled_chains"],
+             acc5=rec5["acceptance_rate"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_bench_protocols(tmp_path):
+    """The protocol functions bench.py --gpus N runs for BASELINE configs 4 and 5 (metropolisengine_amd/protocols.py) at
+    world size 2 over gloo: the per-cycle all-reduce sees both ranks, the overlapped form collects every cycle exactly
+    once, and config 4's adapt_pooled_shape installs the same factor of the covariance pooled over BOTH shards."""
+    n_local, world = 24, 2
+    mp.spawn(_worker_protocols, args=(world, _free_port(), n_local, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "protocols0.npz"), np.load(tmp_path / "protocols1.npz")
+    for r in (r0, r1):
+        assert int(r["ranks5"]) == world and int(r["pooled5"]) == world * n_local
+        assert int(r["ranks4"]) == world and int(r["pooled4"]) == world * n_local
+        assert float(r["rate5"]) > 0 and 0.0 < float(r["acc5"]) < 1.0
+    assert np.array_equal(r0["factor"], r1["factor"])
+    assert float(r0["rate5"]) == float(r1["rate5"])            # max-over-ranks timing: every rank reports the same rate
