@@ -178,11 +178,29 @@ def other_configs(me, rank, world, device, chains_log2, reduce_max, backend, nat
                 "acceptance_rate": engine.acceptance_rate(), "chains_per_gpu": n_chains,
                 "protocol": "(%d x step_all + measure) x %d" % (steps_per_measure, cycles)}
 
+    def cycle_form(engine, n_chains, steps_per_measure, cycles, warm_cycles):
+        """The same protocol through me_cycle: the k sweeps and the measure of a cycle as ONE launch (k_cycle)."""
+        for _ in range(warm_cycles):
+            engine.cycle(steps_per_measure)
+        engine.sync()
+        fused0 = engine.fused_cycles()
+        t0 = time.perf_counter()
+        for _ in range(cycles):
+            engine.cycle(steps_per_measure)
+        engine.sync()
+        dt = reduce_max(time.perf_counter() - t0)
+        return {"chain_steps_per_s": float(n_chains) * world * steps_per_measure * cycles / dt,
+                "acceptance_rate": engine.acceptance_rate(), "chains_per_gpu": n_chains,
+                "launches_per_cycle": 1 if engine.fused_cycles() - fused0 == cycles else 2,
+                "protocol": "cycle(%d) x %d  (= %d x step_all + measure per launch)" % (steps_per_measure, cycles, steps_per_measure)}
+
     a = b = (1.0, 2.0, 4.0, 8.0)
     for dtype in ("f32", "f64"):
-        guarded("config3" + ("" if dtype == "f32" else "_f64"), lambda: protocol(
-            me.MetropolisEngine(me.DiagQuadratic(a, b), None, [0.0] * 4, [0j] * 4, temp=1.0, n_chains=n, seed=2026,
-                                dtype=dtype, device=device, chain_offset=rank * n), n, 10, 100, 60))
+        suffix = "" if dtype == "f32" else "_f64"
+        make3 = lambda: me.MetropolisEngine(me.DiagQuadratic(a, b), None, [0.0] * 4, [0j] * 4, temp=1.0, n_chains=n,
+                                            seed=2026, dtype=dtype, device=device, chain_offset=rank * n)
+        guarded("config3" + suffix, lambda: protocol(make3(), n, 10, 100, 60))
+        guarded("config3_cycle" + suffix, lambda: cycle_form(make3(), n, 10, 100, 60))
     m = np.random.default_rng(5).standard_normal((64, 64))
     amat = m @ m.T / 64 + np.identity(64)
     n4 = n // 2
@@ -235,6 +253,10 @@ def other_configs(me, rank, world, device, chains_log2, reduce_max, backend, nat
             e5.close()
             return rec
         guarded("config5" + ("" if dtype == "f32" else "_f64"), cylinder)
+        guarded("config5_cycle" + ("" if dtype == "f32" else "_f64"), lambda: cycle_form(
+            me.MetropolisEngine(me.UserEnergy("cylinder", src, (1.0, 0.5, 1.0)), me.AbsReal0AtLeast(1.0), [0.1, 0.0],
+                                [0.05] * 7, temp=0.1, n_chains=n5, seed=2026, dtype=dtype, device=device,
+                                chain_offset=rank * n5), n5, 10, 200, 60))
         if backend == "rccl-native" and dtype == "f32":
             guarded("config5_torch_allreduce", lambda: cylinder(None))     # the same cycle through torch.distributed
     return out
@@ -277,6 +299,12 @@ def main():
     ap.add_argument("--pool-backend", default="native", choices=("native", "torch"),
                     help="all-reduce of the pooled moments: the engine's own RCCL communicator, or torch.distributed")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line, the JSON record: RCCL prints a version banner to stdout when a communicator is
+    # created, and child libraries may print too -- everything before the record goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -470,7 +498,8 @@ def main():
             "acceptance_rate": stats["acceptance_rate"],
             "pooled_variance_mean": float(sum(stats["covariance"][i][i] for i in range(N_REAL)) / N_REAL),
         }
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -162,6 +162,14 @@ typedef enum me_step_kind_t {
 } me_step_kind_t;
 int me_step_kind(me_engine *engine, int32_t kind, int32_t n_sweeps);
 int me_measure(me_engine *engine);
+/* One cycle of the reference's driver loop (README.md:41-44: `for j in range(k): step_all()` then `measure()`):
+ * me_cycle(e, k) has exactly the results of me_step(e, k); me_measure(e), but where a fused kernel exists for the engine
+ * (per-chain covariance kept in registers: up to 160 packed entries, step_all sweeps, identity or per-chain shape) it
+ * is ONE launch -- state, energy and width are read once and written once, the sweeps run in registers, mean /
+ * observables / covariance / factors are updated from the registers.  Otherwise the two launches are issued.
+ * me_cycle_stats: how many me_cycle calls of this engine ran as one launch. */
+int me_cycle(me_engine *engine, int32_t n_sweeps);
+int me_cycle_stats(me_engine *engine, uint64_t *fused_cycles);
 /* set_reject_condition (metropolis_engine.py:142-146): the wall predicate is a launch parameter and may be changed
  * between steps (in the reference this setter is the only working way to install one, quirk Q6). */
 int me_set_reject_condition(me_engine *engine, int32_t reject_kind, double reject_bound);

@@ -48,6 +48,8 @@ SYMBOLS = {
     "me_destroy": (ctypes.c_int, [_H]),
     "me_step": (ctypes.c_int, [_H, ctypes.c_int32]),
     "me_measure": (ctypes.c_int, [_H]),
+    "me_cycle": (ctypes.c_int, [_H, ctypes.c_int32]),
+    "me_cycle_stats": (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_uint64)]),
     "me_step_kind": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32]),
     "me_set_reject_condition": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_double]),
     "me_step_injected": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32, _dp, _dp]),

@@ -153,6 +153,7 @@ struct me_engine {
   int n_terms = 1;   // rows of the energy ledger (KernelSet::energy_terms)
   std::vector<double> coef;
   unsigned long long step_index = 0, measure_count = 1;   // counters start at 1 (metropolis_engine.py:72-75)
+  unsigned long long fused_cycles = 0;                    // me_cycle calls that ran as ONE launch (k_cycle)
   // device buffers (SoA: component-major, chain-minor)
   void *x = nullptr, *energy = nullptr, *width = nullptr, *mean = nullptr, *cov = nullptr, *obs_mean = nullptr;
   void *factor = nullptr, *shared_factor = nullptr, *shared_full = nullptr, *shared_image = nullptr, *energy_image = nullptr, *coef_dev = nullptr,
@@ -837,11 +838,9 @@ int me_step_injected(me_engine *e, int32_t kind, int32_t n_sweeps, const double 
   return rc;
 }
 
-int me_measure(me_engine *e) {
-  if (!e) return ME_ERR_INVALID;
-  ME_HIP(e, hipSetDevice(e->device));
-  const unsigned long long count = e->measure_count + 1;   // metropolis_engine.py:343; committed once the launch succeeded
-  MeasureLaunch l;
+namespace {
+// measure() as a launch descriptor: `count` is the counter AFTER the increment (metropolis_engine.py:343)
+void fill_measure_launch(me_engine *e, MeasureLaunch &l, unsigned long long count) {
   l.n_real = e->nr;
   l.n_complex = e->nc;
   l.x = e->x;
@@ -857,8 +856,12 @@ int me_measure(me_engine *e) {
   l.split_widths = (e->width_rows == 3 && !e->widths_synced) ? 1 : 0;
   l.write_factor = (l.update_cov && e->cov_mode == ME_COV_REFERENCE) ? 1 : 0;
   l.grid_blocks = e->grid_blocks;
-  ME_HIP(e, e->ks->measure(l, e->stream));
-  e->measure_count = count;
+}
+
+// host bookkeeping once the measure (or cycle) launch succeeded: the counter, the proposal shape the NEXT steps use, and the
+// time-series row of the traced chains (:350-356)
+int commit_measure(me_engine *e, const MeasureLaunch &l) {
+  e->measure_count = l.measure_count;
   if (l.write_factor) e->cov_kind = CK_PER_CHAIN;
   if (e->trace_chains > 0) {
     const long long cols = e->d + e->n_terms + e->width_rows;
@@ -887,6 +890,48 @@ int me_measure(me_engine *e) {
     }
     e->trace_rows += 1;
   }
+  return ME_OK;
+}
+}  // namespace
+
+int me_measure(me_engine *e) {
+  if (!e) return ME_ERR_INVALID;
+  ME_HIP(e, hipSetDevice(e->device));
+  MeasureLaunch l;
+  fill_measure_launch(e, l, e->measure_count + 1);   // committed once the launch succeeded
+  ME_HIP(e, e->ks->measure(l, e->stream));
+  return commit_measure(e, l);
+}
+
+int me_cycle(me_engine *e, int32_t n_sweeps) {
+  if (!e) return ME_ERR_INVALID;
+  if (n_sweeps <= 0) return fail(e, ME_ERR_INVALID, "n_sweeps must be positive");
+  ME_HIP(e, hipSetDevice(e->device));
+  if (e->ks->cycle) {
+    StepLaunch sl;
+    fill_step_launch(e, sl, n_sweeps);
+    MeasureLaunch ml;
+    fill_measure_launch(e, ml, e->measure_count + 1);
+    ml.split_widths = 0;                 // the sweeps are step_all: afterwards the group widths equal the shared one
+    const hipError_t err = e->ks->cycle(sl, ml, e->stream);
+    if (err == hipSuccess) {
+      e->widths_synced = true;
+      e->step_index += (unsigned long long)n_sweeps;
+      e->proposed += (unsigned long long)e->n * (unsigned long long)n_sweeps;
+      e->fused_cycles += 1;
+      return commit_measure(e, ml);
+    }
+    if (err != hipErrorNotSupported) ME_HIP(e, err);
+    (void)hipGetLastError();
+  }
+  // no fused kernel for this engine / state: the same two launches the caller would have issued
+  const int rc = me_step(e, n_sweeps);
+  return rc != ME_OK ? rc : me_measure(e);
+}
+
+int me_cycle_stats(me_engine *e, uint64_t *fused_cycles) {
+  if (!e || !fused_cycles) return ME_ERR_INVALID;
+  *fused_cycles = e->fused_cycles;
   return ME_OK;
 }
 

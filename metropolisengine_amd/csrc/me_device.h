@@ -547,6 +547,166 @@ static_assert(join_halves((int)0xffff8000u, (int)0xfffffff0u) == 0xffff8000fffff
 #define ME_STREAM_CHUNK_BYTES 128
 #endif
 
+// The pieces of one sweep of ONE chain, state in registers (metropolis_engine.py:209-338, :429-456): draw_step (the Philox
+// block -> normals + accept uniform), propose_registers (x' from the identity shape, a shared factor or the chain's own
+// register-resident factor), decide_step (wall -> energy -> accept rule -> commit -> width adaptation).  run_sweeps strings
+// them together for k_step and k_cycle; k_step's STREAMED-factor form keeps its proposal in the kernel body (that
+// straight-line code over thousands of entries only stays in registers when it is unrolled inside the kernel itself: moved
+// into an inlined function it went to 12 KB of scratch per lane and 13 x the compile time).  All forced inline.
+template <typename R, int NR, int NC, bool INJECT>
+__device__ __forceinline__ void draw_step(const StepArgs<R> &a, long long c, unsigned long long gid, int s,
+                                          R (&g)[2 * ((NR + 2 * NC + 1) / 2)], R &u) {
+  constexpr int D = NR + 2 * NC;
+  constexpr int NW = 2 * ((D + 1) / 2);     // words consumed by the Box-Muller pairs
+  constexpr int NBLK = (NW + 1 + 3) / 4;    // Philox blocks per step (word NW is the accept uniform)
+  using N_ = Num<R>;
+  [[maybe_unused]] const unsigned long long step = a.step_index + (unsigned long long)s;
+  if constexpr (INJECT) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) g[j] = a.inj_normals[((long long)s * D + j) * a.n + c];
+    u = a.inj_uniforms[(long long)s * a.n + c];
+  } else {
+    uint32_t words[4 * NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+      U4 ctr;
+      ctr.x = (uint32_t)gid;
+      ctr.y = (uint32_t)(gid >> 32);
+      ctr.z = (uint32_t)step;
+      ctr.w = ((uint32_t)(step >> 32) << 16) | (uint32_t)b;
+      const U4 o = philox4x32_10(ctr, a.seed_lo, a.seed_hi);
+      words[4 * b + 0] = o.x;
+      words[4 * b + 1] = o.y;
+      words[4 * b + 2] = o.z;
+      words[4 * b + 3] = o.w;
+    }
+#pragma unroll
+    for (int q = 0; q < NW / 2; ++q) N_::normal_pair(words[2 * q], words[2 * q + 1], g[2 * q], g[2 * q + 1]);
+    u = N_::unit(words[NW]);
+  }
+
+}
+
+//   fac(k)   entry k of the proposal factor (per-chain: a coalesced load; shared: a scalar load)
+template <typename R, int NR, int NC, int CK, int GROUP, class Fac>
+__device__ __forceinline__ void propose_registers(const R (&x)[NR + 2 * NC], const R (&g)[2 * ((NR + 2 * NC + 1) / 2)], R w_r, R w_c,
+                                                  Fac &&fac, R (&xp)[NR + 2 * NC]) {
+  constexpr int D = NR + 2 * NC;
+  [[maybe_unused]] constexpr int PR = NR * (NR + 1) / 2;
+  constexpr bool MOVE_REAL = NR > 0 && GROUP != GROUP_COMPLEX;
+  constexpr bool MOVE_COMPLEX = NC > 0 && GROUP != GROUP_REAL;
+  // ---- proposal: x' = x + w_r L_r g_r ; z' = z + w_c L_c (g_re + i g_im)/sqrt2   (:261-302)
+#pragma unroll
+  for (int d = 0; d < D; ++d) xp[d] = x[d];
+  if constexpr (CK == CK_IDENTITY) {
+    if constexpr (MOVE_REAL) {
+#pragma unroll
+      for (int i = 0; i < NR; ++i) xp[i] = x[i] + w_r * g[i];
+    }
+    if constexpr (MOVE_COMPLEX) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        xp[NR + j] = x[NR + j] + w_c * (g[NR + j] * R(0.70710678118654752440));
+        xp[NR + NC + j] = x[NR + NC + j] + w_c * (g[NR + NC + j] * R(0.70710678118654752440));
+      }
+    }
+  } else {
+    if constexpr (MOVE_REAL) {
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        R acc = 0;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) acc += fac(tri(i, j)) * g[j];
+        xp[i] = x[i] + w_r * acc;
+      }
+    }
+    if constexpr (MOVE_COMPLEX) {
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        R are = 0, aim = 0;
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+          const R lre = fac(cre(PR, i, j));
+          const R lim = fac(cim(PR, i, j));
+          const R wre = g[NR + j] * R(0.70710678118654752440), wim = g[NR + NC + j] * R(0.70710678118654752440);
+          are += lre * wre - lim * wim;
+          aim += lre * wim + lim * wre;
+        }
+        const R ld = fac(cdiag(PR, i));
+        are += ld * (g[NR + i] * R(0.70710678118654752440));
+        aim += ld * (g[NR + NC + i] * R(0.70710678118654752440));
+        xp[NR + i] = x[NR + i] + w_c * are;
+        xp[NR + NC + i] = x[NR + NC + i] + w_c * aim;
+      }
+    }
+  }
+
+}
+
+template <typename R, int NR, int NC, class Energy, int CK, int GROUP, class Ledger>
+__device__ __forceinline__ void decide_step(const StepArgs<R> &a, const Energy &en, bool stale_total, R u,
+                                            const R (&g)[2 * ((NR + 2 * NC + 1) / 2)], R (&x)[NR + 2 * NC], const R (&xp)[NR + 2 * NC],
+                                            Ledger &ledger, R &total_q5, R &w, R &w_r, R &w_c, unsigned int &wave_accepted,
+                                            bool &bad_energy) {
+  [[maybe_unused]] constexpr int D = NR + 2 * NC;
+  constexpr bool MOVE_REAL = NR > 0 && GROUP != GROUP_COMPLEX;
+  constexpr bool MOVE_COMPLEX = NC > 0 && GROUP != GROUP_REAL;
+  using N_ = Num<R>;
+  // ---- hard wall before the energy (:247-249), energy, accept rule (:319-338)
+  bool rejected = false;
+  if (a.reject_kind == ME_REJECT_ABS_REAL0_GE) rejected = !(N_::abs_(xp[0]) < a.reject_bound);
+  else if (a.reject_kind == ME_REJECT_USER) rejected = energy_reject(en, xp, 0);
+  R terms_new[Ledger::T];
+  const R e_new = ledger.propose(en, xp, terms_new);
+  const R diff = e_new - (stale_total ? total_q5 : ledger.partial());
+  bool accept = diff <= R(0);
+  if (a.temp > R(0)) accept = accept || N_::uphill(u, diff, a.inv_temp, a.inv_temp_log2e);
+  accept = accept && !rejected;
+  bad_energy |= (!rejected && !N_::finite(e_new));
+  if constexpr (CK == CK_IDENTITY) {
+    // commit as x += (accept ? w : 0) g: the same fma that formed x' (bit-identical on acceptance, exact identity on
+    // rejection since the draws are finite), and it pairs up as v_pk_fma_f32 where 16 v_cndmask_b32 would not
+    const R wa_r = accept ? w_r : R(0), wa_c = accept ? w_c : R(0);
+    if constexpr (MOVE_REAL) {
+#pragma unroll
+      for (int i = 0; i < NR; ++i) x[i] = x[i] + wa_r * g[i];
+    }
+    if constexpr (MOVE_COMPLEX) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        x[NR + j] = x[NR + j] + wa_c * (g[NR + j] * R(0.70710678118654752440));
+        x[NR + NC + j] = x[NR + NC + j] + wa_c * (g[NR + NC + j] * R(0.70710678118654752440));
+      }
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = accept ? xp[d] : x[d];
+  }
+  if (stale_total) total_q5 = accept ? e_new : total_q5;
+  else ledger.commit(accept, terms_new);
+  // ---- Robbins-Monro width update (:429-456); step_all of a mixed engine mirrors it into both groups (:436-437)
+  w = N_::adapt(w, accept, a.ratio, a.p, a.damping, a.up, a.down);
+  if constexpr (GROUP == GROUP_ALL) w_r = w_c = w;
+  else if constexpr (GROUP == GROUP_REAL) w_r = w;
+  else w_c = w;
+  wave_accepted += (unsigned int)__popcll(__ballot(accept));
+}
+
+// n_sweeps sweeps with a register-resident proposal shape:  x, ledger / total_q5, w, w_r, w_c are updated in place
+template <typename R, int NR, int NC, class Energy, int CK, bool INJECT, int GROUP, class Ledger, class Fac>
+__device__ __forceinline__ void run_sweeps(const StepArgs<R> &a, const Energy &en, long long c, unsigned long long gid,
+                                           bool stale_total, R (&x)[NR + 2 * NC], Ledger &ledger, R &total_q5, R &w, R &w_r,
+                                           R &w_c, Fac &&fac, unsigned int &wave_accepted, bool &bad_energy) {
+  constexpr int D = NR + 2 * NC;
+  constexpr int NW = 2 * ((D + 1) / 2);
+  for (int s = 0; s < a.n_sweeps; ++s) {
+    R g[NW], u, xp[D];
+    draw_step<R, NR, NC, INJECT>(a, c, gid, s, g, u);
+    propose_registers<R, NR, NC, CK, GROUP>(x, g, w_r, w_c, fac, xp);
+    decide_step<R, NR, NC, Energy, CK, GROUP>(a, en, stale_total, u, g, x, xp, ledger, total_q5, w, w_r, w_c, wave_accepted, bad_energy);
+  }
+}
+
 // INJECT = true replaces the Philox draws by caller-provided streams (test hook: replays the reference's golden
 // trajectories, tests/golden/, through the very same proposal / accept / adapt code).
 // Tuning knobs (experiments; defaults are the shipped configuration):
@@ -568,12 +728,7 @@ static_assert(join_halves((int)0xffff8000u, (int)0xfffffff0u) == 0xffff8000fffff
 template <typename R, int NR, int NC, class Energy, int CK, bool INJECT = false, int GROUP = GROUP_ALL, bool NTS = false>
 __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   constexpr int D = NR + 2 * NC;
-  constexpr int PR = NR * (NR + 1) / 2;
-  constexpr int NW = 2 * ((D + 1) / 2);     // words consumed by the Box-Muller pairs
-  constexpr int NBLK = (NW + 1 + 3) / 4;    // Philox blocks per step (word NW is the accept uniform)
   constexpr bool MIXED = NR > 0 && NC > 0;
-  constexpr bool MOVE_REAL = NR > 0 && GROUP != GROUP_COMPLEX;
-  constexpr bool MOVE_COMPLEX = NC > 0 && GROUP != GROUP_REAL;
   static_assert(GROUP == GROUP_ALL || MIXED, "group-wise kernels exist for mixed engines only");
   using N_ = Num<R>;
 
@@ -627,51 +782,38 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
       else return a.factor[k];
     };
 
-    for (int s = 0; s < a.n_sweeps; ++s) {
-      const unsigned long long step = a.step_index + (unsigned long long)s;
-      R g[NW];
-      R u;
-      if constexpr (INJECT) {
+    if constexpr (STREAM_FACTOR) {
+      constexpr int NW = 2 * ((D + 1) / 2);
+      for (int s = 0; s < a.n_sweeps; ++s) {
+        // (draw and decide are spelled out here instead of calling draw_step / decide_step: with the arrays handed to inlined
+        // functions by reference this kernel -- thousands of unrolled entries -- kept 1.4 KB of them in scratch)
+        static_assert(!INJECT, "the streamed-factor form has no replay hook");
+        constexpr int NBLK = (NW + 1 + 3) / 4;
+        const unsigned long long step = a.step_index + (unsigned long long)s;
+        R g[NW];
+        R u_accept;
+        {
+          uint32_t words[4 * NBLK];
 #pragma unroll
-        for (int j = 0; j < D; ++j) g[j] = a.inj_normals[((long long)s * D + j) * a.n + c];
-        u = a.inj_uniforms[(long long)s * a.n + c];
-      } else {
-        uint32_t words[4 * NBLK];
-#pragma unroll
-        for (int b = 0; b < NBLK; ++b) {
-          U4 ctr;
-          ctr.x = (uint32_t)gid;
-          ctr.y = (uint32_t)(gid >> 32);
-          ctr.z = (uint32_t)step;
-          ctr.w = ((uint32_t)(step >> 32) << 16) | (uint32_t)b;
-          const U4 o = philox4x32_10(ctr, a.seed_lo, a.seed_hi);
-          words[4 * b + 0] = o.x;
-          words[4 * b + 1] = o.y;
-          words[4 * b + 2] = o.z;
-          words[4 * b + 3] = o.w;
-        }
-#pragma unroll
-        for (int q = 0; q < NW / 2; ++q) N_::normal_pair(words[2 * q], words[2 * q + 1], g[2 * q], g[2 * q + 1]);
-        u = N_::unit(words[NW]);
-      }
-
-      // ---- proposal: x' = x + w_r L_r g_r ; z' = z + w_c L_c (g_re + i g_im)/sqrt2   (:261-302)
-      R xp[D];
-#pragma unroll
-      for (int d = 0; d < D; ++d) xp[d] = x[d];
-      if constexpr (CK == CK_IDENTITY) {
-        if constexpr (MOVE_REAL) {
-#pragma unroll
-          for (int i = 0; i < NR; ++i) xp[i] = x[i] + w_r * g[i];
-        }
-        if constexpr (MOVE_COMPLEX) {
-#pragma unroll
-          for (int j = 0; j < NC; ++j) {
-            xp[NR + j] = x[NR + j] + w_c * (g[NR + j] * R(0.70710678118654752440));
-            xp[NR + NC + j] = x[NR + NC + j] + w_c * (g[NR + NC + j] * R(0.70710678118654752440));
+          for (int b = 0; b < NBLK; ++b) {
+            U4 ctr;
+            ctr.x = (uint32_t)gid;
+            ctr.y = (uint32_t)(gid >> 32);
+            ctr.z = (uint32_t)step;
+            ctr.w = ((uint32_t)(step >> 32) << 16) | (uint32_t)b;
+            const U4 o = philox4x32_10(ctr, a.seed_lo, a.seed_hi);
+            words[4 * b + 0] = o.x;
+            words[4 * b + 1] = o.y;
+            words[4 * b + 2] = o.z;
+            words[4 * b + 3] = o.w;
           }
+#pragma unroll
+          for (int q = 0; q < NW / 2; ++q) N_::normal_pair(words[2 * q], words[2 * q + 1], g[2 * q], g[2 * q + 1]);
+          u_accept = N_::unit(words[NW]);
         }
-      } else if constexpr (STREAM_FACTOR) {
+        R xp[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) xp[d] = x[d];
         // Packed factors too large for registers (more than 160 entries; pure real spaces, e.g. 64 parameters = 2 080
         // entries = 8-16 KB per chain and step).  The chain's entries are one run of its tile (64 values apart), read
         // exactly once per step -- the kernel is a STREAM and lives on bytes in flight: with one wavefront per SIMD a
@@ -719,75 +861,27 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
           });
           xp[i] = x[i] + w_r * acc;
         });
-      } else {
-        if constexpr (MOVE_REAL) {
-#pragma unroll
-          for (int i = 0; i < NR; ++i) {
-            R acc = 0;
-#pragma unroll
-            for (int j = 0; j <= i; ++j) acc += fac(tri(i, j)) * g[j];
-            xp[i] = x[i] + w_r * acc;
-          }
-        }
-        if constexpr (MOVE_COMPLEX) {
-#pragma unroll
-          for (int i = 0; i < NC; ++i) {
-            R are = 0, aim = 0;
-#pragma unroll
-            for (int j = 0; j < i; ++j) {
-              const R lre = fac(cre(PR, i, j));
-              const R lim = fac(cim(PR, i, j));
-              const R wre = g[NR + j] * R(0.70710678118654752440), wim = g[NR + NC + j] * R(0.70710678118654752440);
-              are += lre * wre - lim * wim;
-              aim += lre * wim + lim * wre;
-            }
-            const R ld = fac(cdiag(PR, i));
-            are += ld * (g[NR + i] * R(0.70710678118654752440));
-            aim += ld * (g[NR + NC + i] * R(0.70710678118654752440));
-            xp[NR + i] = x[NR + i] + w_c * are;
-            xp[NR + NC + i] = x[NR + NC + i] + w_c * aim;
-          }
-        }
-      }
-
-      // ---- hard wall before the energy (:247-249), energy, accept rule (:319-338)
-      bool rejected = false;
-      if (a.reject_kind == ME_REJECT_ABS_REAL0_GE) rejected = !(N_::abs_(xp[0]) < a.reject_bound);
-      else if (a.reject_kind == ME_REJECT_USER) rejected = energy_reject(en, xp, 0);
-      R terms_new[Ledger::T];
-      const R e_new = ledger.propose(en, xp, terms_new);
-      const R diff = e_new - (stale_total ? total_q5 : ledger.partial());
-      bool accept = diff <= R(0);
-      if (a.temp > R(0)) accept = accept || N_::uphill(u, diff, a.inv_temp, a.inv_temp_log2e);
-      accept = accept && !rejected;
-      bad_energy |= (!rejected && !N_::finite(e_new));
-      if constexpr (CK == CK_IDENTITY) {
-        // commit as x += (accept ? w : 0) g: the same fma that formed x' (bit-identical on acceptance, exact identity on
-        // rejection since the draws are finite), and it pairs up as v_pk_fma_f32 where 16 v_cndmask_b32 would not
-        const R wa_r = accept ? w_r : R(0), wa_c = accept ? w_c : R(0);
-        if constexpr (MOVE_REAL) {
-#pragma unroll
-          for (int i = 0; i < NR; ++i) x[i] = x[i] + wa_r * g[i];
-        }
-        if constexpr (MOVE_COMPLEX) {
-#pragma unroll
-          for (int j = 0; j < NC; ++j) {
-            x[NR + j] = x[NR + j] + wa_c * (g[NR + j] * R(0.70710678118654752440));
-            x[NR + NC + j] = x[NR + NC + j] + wa_c * (g[NR + NC + j] * R(0.70710678118654752440));
-          }
-        }
-      } else {
+        // ---- hard wall before the energy (:247-249), energy, accept rule (:319-338), commit, width (decide_step's code)
+        bool rejected = false;
+        if (a.reject_kind == ME_REJECT_ABS_REAL0_GE) rejected = !(N_::abs_(xp[0]) < a.reject_bound);
+        else if (a.reject_kind == ME_REJECT_USER) rejected = energy_reject(en, xp, 0);
+        R terms_new[Ledger::T];
+        const R e_new = ledger.propose(en, xp, terms_new);
+        const R diff = e_new - (stale_total ? total_q5 : ledger.partial());
+        bool accept = diff <= R(0);
+        if (a.temp > R(0)) accept = accept || N_::uphill(u_accept, diff, a.inv_temp, a.inv_temp_log2e);
+        accept = accept && !rejected;
+        bad_energy |= (!rejected && !N_::finite(e_new));
 #pragma unroll
         for (int d = 0; d < D; ++d) x[d] = accept ? xp[d] : x[d];
+        if (stale_total) total_q5 = accept ? e_new : total_q5;
+        else ledger.commit(accept, terms_new);
+        w = N_::adapt(w, accept, a.ratio, a.p, a.damping, a.up, a.down);
+        w_r = w_c = w;
+        wave_accepted += (unsigned int)__popcll(__ballot(accept));
       }
-      if (stale_total) total_q5 = accept ? e_new : total_q5;
-      else ledger.commit(accept, terms_new);
-      // ---- Robbins-Monro width update (:429-456); step_all of a mixed engine mirrors it into both groups (:436-437)
-      w = N_::adapt(w, accept, a.ratio, a.p, a.damping, a.up, a.down);
-      if constexpr (GROUP == GROUP_ALL) w_r = w_c = w;
-      else if constexpr (GROUP == GROUP_REAL) w_r = w;
-      else w_c = w;
-      wave_accepted += (unsigned int)__popcll(__ballot(accept));
+    } else {
+      run_sweeps<R, NR, NC, Energy, CK, INJECT, GROUP>(a, en, c, gid, stale_total, x, ledger, total_q5, w, w_r, w_c, fac, wave_accepted, bad_energy);
     }
     bad_width |= !(w > R(0));
 #pragma unroll
@@ -916,13 +1010,175 @@ __device__ __forceinline__ void cholesky_packed(R (&m)[NR * (NR + 1) / 2 + NC * 
 // resident in the Infinity Cache between launches no longer fit together with it.  Measured at 2^20 x (16,0): packed
 // fields nt 468 -> 375 us, means nt on top of that 375 -> 410 us (x + means + observables = 256 MB still profit from the
 // cache); at 2^19 x (64,0), means only: 225 -> 190 us with nt (537 MB: keeping x resident for the next k_step wins).
-template <typename R, int NR, int NC, bool PER_CHAIN_COV, bool FUSED, bool NT, bool NTM>
-__global__ void __launch_bounds__(kStepThreads, ME_MEASURE_WAVES) k_measure(MeasureArgs<R> a) {
+// measure() of ONE chain whose state x is in registers: running mean (:404-410), observables (:458-463, :412-414),
+// covariance recursion (:416-427, one-pass form above) and the refresh of the chain's proposal factors.  Shared by
+// k_measure (loads x) and k_cycle (x comes straight out of the sweeps); forced inline.  widths(w_real, w_cplx) supplies
+// the group widths of the epsilon term (:418, :425) -- a field load in k_measure, registers in k_cycle.
+template <typename R, int NR, int NC, bool PER_CHAIN_COV, bool FUSED, bool NT, bool NTM, class WidthFn>
+__device__ __forceinline__ void measure_chain(const MeasureArgs<R> &a, long long c, const R (&x)[NR + 2 * NC], const Field<R> &fmean,
+                                              const Field<R> &fobs, const TiledField<R> &fcov, const TiledField<R> &ffac,
+                                              [[maybe_unused]] R (*s_delta)[kStepThreads], WidthFn &&widths, bool &bad_pivot) {
   constexpr int D = NR + 2 * NC;
   constexpr int PR = NR * (NR + 1) / 2;
   constexpr int P = PR + NC * NC;
   constexpr int NOBS = 2 * NR + NC;
+  constexpr bool STREAM = PER_CHAIN_COV && P > kMaxPackedInRegisters;
   using N_ = Num<R>;
+  const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
+  [[maybe_unused]] const unsigned int toff = tiled_offset<R>(c, P);      // the chain's place in the packed fields
+  // Every phase issues ALL its loads before its first store: the compiler cannot prove that a store to one field does
+  // not alias the next load of another, so interleaved load-update-store sequences were emitted strictly in order
+  // with two loads in flight per wavefront (k_measure<64,0> ran at 0.36 of the HBM peak that way).
+  R delta[D];
+  {
+    R mu[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) mu[d] = packed_load<NTM>(fmean, d, coff);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if constexpr (STREAM) s_delta[d][threadIdx.x] = x[d] - mu[d];   // parked in LDS, see the streaming path below
+      else delta[d] = x[d] - mu[d];
+      packed_store<NTM>(fmean, d, coff, mu[d] * a.keep + x[d] * a.inv_i);   // :404-410
+    }
+  }
+  // observables [|x_r|, |z_c|, x_r^2] and their running mean (:458-463, :412-414), in batches of kBatch
+  constexpr int kBatch = 32;
+#pragma unroll
+  for (int k0 = 0; k0 < NOBS; k0 += kBatch) {
+    R m[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u)
+      if (k0 + u < NOBS) m[u] = packed_load<NTM>(fobs, k0 + u, coff);
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const int k = k0 + u;
+      if (k < NOBS) {
+        R o;
+        if (k < NR) o = N_::abs_(x[k]);
+        else if (k < NR + NC) o = N_::sqrt_(x[k] * x[k] + x[k + NC] * x[k + NC]);
+        else o = x[k - NR - NC] * x[k - NR - NC];
+        packed_store<NTM>(fobs, k, coff, m[u] * a.keep + o * a.inv_i);
+      }
+    }
+  }
+  if constexpr (PER_CHAIN_COV) {
+    if (a.update_cov) {
+      // :418, :425 -- each block uses its own group's width; they coincide unless group steps made them differ
+      R w_real, w_cplx;
+      widths(w_real, w_cplx);
+      const R eps = w_real * w_real * a.inv_i;
+      const R eps_c = w_cplx * w_cplx * a.inv_i;
+      if constexpr (STREAM) {
+        // delta is parked in LDS (lane-linear, conflict-free) so that the walk over the packed entries can be a
+        // ROLLED loop: unrolled, 2 080 entries are ~100 KB of code and the kernel becomes instruction-fetch bound.
+        // One 64-bit pointer per lane steps by whole rows (the packed order is exactly the loop order).
+        // tile-major: the chain's entries lie 64 values apart from the start of its tile
+        R *p = a.cov + (c >> 6) * (long long)P * 64 + (c & 63);
+        constexpr long long ts = 64;
+        for (int i = 0; i < NR; ++i) {
+          const R di = s_delta[i][threadIdx.x];
+          int j = 0;
+          // batches of 16 (then 4) entries: all loads first (a store to p[.] would otherwise fence the next load, the compiler
+          // cannot prove the rows distinct), then the updates
+          for (; j + 16 <= i; j += 16) {
+            R v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = p[u * ts];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) p[u * ts] = v[u] * a.cov_keep + di * s_delta[j + u][threadIdx.x] * a.inv_i;
+            p += 16 * ts;
+          }
+          for (; j + 4 <= i; j += 4) {
+            R v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = p[u * ts];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u * ts] = v[u] * a.cov_keep + di * s_delta[j + u][threadIdx.x] * a.inv_i;
+            p += 4 * ts;
+          }
+          for (; j < i; ++j) {
+            *p = *p * a.cov_keep + di * s_delta[j][threadIdx.x] * a.inv_i;
+            p += ts;
+          }
+          *p = *p * a.cov_keep + di * di * a.inv_i + eps;
+          p += ts;
+        }
+        for (int i = 0; i < NC; ++i) {
+          const R ai = s_delta[NR + i][threadIdx.x], bi = s_delta[NR + NC + i][threadIdx.x];
+          int j = 0;
+          for (; j + 8 <= i; j += 8) {          // eight (Re, Im) pairs: sixteen loads, then the updates
+            R v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = p[u * ts];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const R aj = s_delta[NR + j + u][threadIdx.x], bj = s_delta[NR + NC + j + u][threadIdx.x];
+              p[(2 * u) * ts] = v[2 * u] * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
+              p[(2 * u + 1) * ts] = v[2 * u + 1] * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
+            }
+            p += 16 * ts;
+          }
+          for (; j < i; ++j) {
+            const R aj = s_delta[NR + j][threadIdx.x], bj = s_delta[NR + NC + j][threadIdx.x];
+            const R re = p[0], im = p[ts];
+            p[0] = re * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
+            p[ts] = im * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
+            p += 2 * ts;
+          }
+          *p = *p * a.cov_keep + (ai * ai + bi * bi) * a.inv_i + eps_c;
+          p += ts;
+        }
+      } else {
+      // the packed matrix is read whole, then updated and written back (FUSED keeps it for the Cholesky anyway)
+      R m[P];
+#pragma unroll
+      for (int k = 0; k < P; ++k) m[k] = packed_load<NT>(fcov, k, toff);
+#pragma unroll
+      for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+          const int k = tri(i, j);
+          R v = m[k] * a.cov_keep + delta[i] * delta[j] * a.inv_i;
+          if (i == j) v += eps;
+          packed_store<NT>(fcov, k, toff, v);
+          m[k] = v;
+        }
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const R ai = delta[NR + i], bi = delta[NR + NC + i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+          const R aj = delta[NR + j], bj = delta[NR + NC + j];
+          const int kr = cre(PR, i, j), ki = cim(PR, i, j);
+          const R vr = m[kr] * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
+          const R vi = m[ki] * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
+          packed_store<NT>(fcov, kr, toff, vr);
+          packed_store<NT>(fcov, ki, toff, vi);
+          m[kr] = vr;
+          m[ki] = -vi;   // the proposals use conj(K) (quirk Q3, :292-298)
+        }
+        const int kd = cdiag(PR, i);
+        const R vd = m[kd] * a.cov_keep + (ai * ai + bi * bi) * a.inv_i + eps_c;
+        packed_store<NT>(fcov, kd, toff, vd);
+        m[kd] = vd;
+      }
+      if constexpr (FUSED) {
+        if (a.write_factor) {
+          cholesky_packed<R, NR, NC>(m, bad_pivot);
+#pragma unroll
+          for (int k = 0; k < P; ++k) packed_store<NT>(ffac, k, toff, m[k]);
+        }
+      }
+      }   // !STREAM
+    }
+  }
+}
+
+template <typename R, int NR, int NC, bool PER_CHAIN_COV, bool FUSED, bool NT, bool NTM>
+__global__ void __launch_bounds__(kStepThreads, ME_MEASURE_WAVES) k_measure(MeasureArgs<R> a) {
+  constexpr int D = NR + 2 * NC;
+  constexpr int P = NR * (NR + 1) / 2 + NC * NC;
+  constexpr int NOBS = 2 * NR + NC;
   bool bad_pivot = false;
   const long long stride = (long long)gridDim.x * kStepThreads;
   const Field<R> fx(a.x, a.n, D), fw(a.width, a.n, (NR > 0 && NC > 0) ? 3 : 1), fmean(a.mean, a.n, D), fobs(a.obs_mean, a.n, NOBS);
@@ -934,158 +1190,91 @@ __global__ void __launch_bounds__(kStepThreads, ME_MEASURE_WAVES) k_measure(Meas
   __shared__ R s_delta[STREAM ? D : 1][kStepThreads];
   for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
-    [[maybe_unused]] const unsigned int toff = tiled_offset<R>(c, P);      // the chain's place in the packed fields
-    // Every phase issues ALL its loads before its first store: the compiler cannot prove that a store to one field does
-    // not alias the next load of another, so interleaved load-update-store sequences were emitted strictly in order
-    // with two loads in flight per wavefront (k_measure<64,0> ran at 0.36 of the HBM peak that way).
-    R x[D], delta[D];
-    {
-      R mu[D];
+    R x[D];
 #pragma unroll
-      for (int d = 0; d < D; ++d) x[d] = fx.load(d, coff);
-#pragma unroll
-      for (int d = 0; d < D; ++d) mu[d] = packed_load<NTM>(fmean, d, coff);
-#pragma unroll
-      for (int d = 0; d < D; ++d) {
-        if constexpr (STREAM) s_delta[d][threadIdx.x] = x[d] - mu[d];   // parked in LDS, see the streaming path below
-        else delta[d] = x[d] - mu[d];
-        packed_store<NTM>(fmean, d, coff, mu[d] * a.keep + x[d] * a.inv_i);   // :404-410
-      }
-    }
-    // observables [|x_r|, |z_c|, x_r^2] and their running mean (:458-463, :412-414), in batches of kBatch
-    constexpr int kBatch = 32;
-#pragma unroll
-    for (int k0 = 0; k0 < NOBS; k0 += kBatch) {
-      R m[kBatch];
-#pragma unroll
-      for (int u = 0; u < kBatch; ++u)
-        if (k0 + u < NOBS) m[u] = packed_load<NTM>(fobs, k0 + u, coff);
-#pragma unroll
-      for (int u = 0; u < kBatch; ++u) {
-        const int k = k0 + u;
-        if (k < NOBS) {
-          R o;
-          if (k < NR) o = N_::abs_(x[k]);
-          else if (k < NR + NC) o = N_::sqrt_(x[k] * x[k] + x[k + NC] * x[k + NC]);
-          else o = x[k - NR - NC] * x[k - NR - NC];
-          packed_store<NTM>(fobs, k, coff, m[u] * a.keep + o * a.inv_i);
-        }
-      }
-    }
-    if constexpr (PER_CHAIN_COV) {
-      if (a.update_cov) {
-        // :418, :425 -- each block uses its own group's width; they coincide unless group steps made them differ
-        constexpr bool MIXED = NR > 0 && NC > 0;
-        const R w_real = fw.load((MIXED && a.split_widths) ? 1 : 0, coff);
-        const R w_cplx = fw.load((MIXED && a.split_widths) ? 2 : 0, coff);
-        const R eps = w_real * w_real * a.inv_i;
-        const R eps_c = w_cplx * w_cplx * a.inv_i;
-        if constexpr (STREAM) {
-          // delta is parked in LDS (lane-linear, conflict-free) so that the walk over the packed entries can be a
-          // ROLLED loop: unrolled, 2 080 entries are ~100 KB of code and the kernel becomes instruction-fetch bound.
-          // One 64-bit pointer per lane steps by whole rows (the packed order is exactly the loop order).
-          // tile-major: the chain's entries lie 64 values apart from the start of its tile
-          R *p = a.cov + (c >> 6) * (long long)P * 64 + (c & 63);
-          constexpr long long ts = 64;
-          for (int i = 0; i < NR; ++i) {
-            const R di = s_delta[i][threadIdx.x];
-            int j = 0;
-            // batches of 16 (then 4) entries: all loads first (a store to p[.] would otherwise fence the next load, the compiler
-            // cannot prove the rows distinct), then the updates
-            for (; j + 16 <= i; j += 16) {
-              R v[16];
-#pragma unroll
-              for (int u = 0; u < 16; ++u) v[u] = p[u * ts];
-#pragma unroll
-              for (int u = 0; u < 16; ++u) p[u * ts] = v[u] * a.cov_keep + di * s_delta[j + u][threadIdx.x] * a.inv_i;
-              p += 16 * ts;
-            }
-            for (; j + 4 <= i; j += 4) {
-              R v[4];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) v[u] = p[u * ts];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) p[u * ts] = v[u] * a.cov_keep + di * s_delta[j + u][threadIdx.x] * a.inv_i;
-              p += 4 * ts;
-            }
-            for (; j < i; ++j) {
-              *p = *p * a.cov_keep + di * s_delta[j][threadIdx.x] * a.inv_i;
-              p += ts;
-            }
-            *p = *p * a.cov_keep + di * di * a.inv_i + eps;
-            p += ts;
-          }
-          for (int i = 0; i < NC; ++i) {
-            const R ai = s_delta[NR + i][threadIdx.x], bi = s_delta[NR + NC + i][threadIdx.x];
-            int j = 0;
-            for (; j + 8 <= i; j += 8) {          // eight (Re, Im) pairs: sixteen loads, then the updates
-              R v[16];
-#pragma unroll
-              for (int u = 0; u < 16; ++u) v[u] = p[u * ts];
-#pragma unroll
-              for (int u = 0; u < 8; ++u) {
-                const R aj = s_delta[NR + j + u][threadIdx.x], bj = s_delta[NR + NC + j + u][threadIdx.x];
-                p[(2 * u) * ts] = v[2 * u] * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
-                p[(2 * u + 1) * ts] = v[2 * u + 1] * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
-              }
-              p += 16 * ts;
-            }
-            for (; j < i; ++j) {
-              const R aj = s_delta[NR + j][threadIdx.x], bj = s_delta[NR + NC + j][threadIdx.x];
-              const R re = p[0], im = p[ts];
-              p[0] = re * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
-              p[ts] = im * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
-              p += 2 * ts;
-            }
-            *p = *p * a.cov_keep + (ai * ai + bi * bi) * a.inv_i + eps_c;
-            p += ts;
-          }
-        } else {
-        // the packed matrix is read whole, then updated and written back (FUSED keeps it for the Cholesky anyway)
-        R m[P];
-#pragma unroll
-        for (int k = 0; k < P; ++k) m[k] = packed_load<NT>(fcov, k, toff);
-#pragma unroll
-        for (int i = 0; i < NR; ++i)
-#pragma unroll
-          for (int j = 0; j <= i; ++j) {
-            const int k = tri(i, j);
-            R v = m[k] * a.cov_keep + delta[i] * delta[j] * a.inv_i;
-            if (i == j) v += eps;
-            packed_store<NT>(fcov, k, toff, v);
-            m[k] = v;
-          }
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-          const R ai = delta[NR + i], bi = delta[NR + NC + i];
-#pragma unroll
-          for (int j = 0; j < i; ++j) {
-            const R aj = delta[NR + j], bj = delta[NR + NC + j];
-            const int kr = cre(PR, i, j), ki = cim(PR, i, j);
-            const R vr = m[kr] * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
-            const R vi = m[ki] * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
-            packed_store<NT>(fcov, kr, toff, vr);
-            packed_store<NT>(fcov, ki, toff, vi);
-            m[kr] = vr;
-            m[ki] = -vi;   // the proposals use conj(K) (quirk Q3, :292-298)
-          }
-          const int kd = cdiag(PR, i);
-          const R vd = m[kd] * a.cov_keep + (ai * ai + bi * bi) * a.inv_i + eps_c;
-          packed_store<NT>(fcov, kd, toff, vd);
-          m[kd] = vd;
-        }
-        if constexpr (FUSED) {
-          if (a.write_factor) {
-            cholesky_packed<R, NR, NC>(m, bad_pivot);
-#pragma unroll
-            for (int k = 0; k < P; ++k) packed_store<NT>(ffac, k, toff, m[k]);
-          }
-        }
-        }   // !STREAM
-      }
-    }
+    for (int d = 0; d < D; ++d) x[d] = fx.load(d, coff);
+    measure_chain<R, NR, NC, PER_CHAIN_COV, FUSED, NT, NTM>(a, c, x, fmean, fobs, fcov, ffac, s_delta, [&](R &w_real, R &w_cplx) {
+      constexpr bool MIXED = NR > 0 && NC > 0;
+      w_real = fw.load((MIXED && a.split_widths) ? 1 : 0, coff);
+      w_cplx = fw.load((MIXED && a.split_widths) ? 2 : 0, coff);
+    }, bad_pivot);
   }
   if (bad_pivot) atomicOr(a.status, (unsigned int)ST_BAD_PIVOT);
+}
+
+// ------------------------------------------------------------------------------------------------ k_cycle
+// One cycle of the reference's driver loop (README.md:41-44: k x step_all(), then measure()) in ONE launch: the chain's
+// state, energy and width are loaded once, the n_sweeps sweeps run in registers (run_sweeps, exactly k_step's), the
+// running mean / observables / covariance are updated from the registers and the proposal factors refreshed
+// (measure_chain, exactly k_measure's), and everything is stored once.  Against n_sweeps one-sweep launches plus a measure
+// launch this removes n_sweeps - 1 round trips of the state and the measure's re-read of x and the width; the results are
+// those of `me_step(e, n_sweeps); me_measure(e)` (same code, same order of operations).
+// CK: CK_IDENTITY / CK_SHARED (before the 50th measure, or cov_mode fixed / pooled) or CK_PER_CHAIN (each chain's own
+// factor, read once per launch).  NT / NTM: cache policy of the packed fields / the running means, as in k_measure; NT
+// also covers the factor read of the sweeps.  Packed matrices up to kMaxPackedInRegisters entries.
+template <typename R, int NR, int NC, class Energy, int CK, bool NT, bool NTM>
+__global__ void ME_STEP_BOUNDS k_cycle(StepArgs<R> a, MeasureArgs<R> ma, Energy en) {
+  constexpr int D = NR + 2 * NC;
+  constexpr int P = NR * (NR + 1) / 2 + NC * NC;
+  constexpr int NOBS = 2 * NR + NC;
+  constexpr bool MIXED = NR > 0 && NC > 0;
+  static_assert(P <= kMaxPackedInRegisters, "k_cycle keeps the packed matrix in registers");
+  static_assert(CK == CK_IDENTITY || CK == CK_SHARED || CK == CK_PER_CHAIN, "NT selects the non-temporal factor read");
+  constexpr int CKX = CK == CK_PER_CHAIN ? (NT ? CK_PER_CHAIN_NT : CK_PER_CHAIN) : CK;
+  using N_ = Num<R>;
+  N_::prepare();
+  energy_prepare(en, 0);
+  unsigned int wave_accepted = 0;
+  bool bad_energy = false, bad_width = false, bad_pivot = false;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  using Ledger = EnergyLedger<R, Energy, GROUP_ALL>;
+  const Field<R> fx(a.x, a.n, D), fe(a.energy, a.n, Ledger::T + (MIXED ? 1 : 0)), fw(a.width, a.n, MIXED ? 3 : 1);
+  const Field<R> fmean(ma.mean, a.n, D), fobs(ma.obs_mean, a.n, NOBS);
+  const TiledField<R> fcov(ma.cov, a.n, P), ffac(ma.factor, a.n, P);
+  const bool stale_total = MIXED && a.stale_total != 0;
+  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < a.n; c += stride) {
+    const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
+    R x[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = fx.load(d, coff);
+    Ledger ledger;
+    R total_q5 = R(0);
+    if (stale_total) total_q5 = fe.load(Ledger::T, coff);
+    else ledger.load(fe, coff);
+    R w = fw.load(0, coff);
+    R w_r = w, w_c = w;
+    if constexpr (MIXED) {
+      if (a.split_widths) {
+        w_r = fw.load(GROUP_REAL, coff);
+        w_c = fw.load(GROUP_COMPLEX, coff);
+      }
+    }
+    const unsigned long long gid = a.chain_offset + (unsigned long long)c;
+    [[maybe_unused]] const unsigned int toff = tiled_offset<R>(c, P);
+    auto fac = [&](int k) -> R {
+      if constexpr (CK == CK_PER_CHAIN) return packed_load<NT>(ffac, k, toff);
+      else return a.factor[k];
+    };
+    run_sweeps<R, NR, NC, Energy, CKX, false, GROUP_ALL>(a, en, c, gid, stale_total, x, ledger, total_q5, w, w_r, w_c, fac,
+                                                         wave_accepted, bad_energy);
+    bad_width |= !(w > R(0));
+    // the state goes out first: a block of stores in front of measure_chain's loads costs nothing, and x dies as soon as the
+    // means and observables are formed
+#pragma unroll
+    for (int d = 0; d < D; ++d) fx.store(d, coff, x[d]);
+    if (stale_total) fe.store(Ledger::T, coff, total_q5);
+    else ledger.store(fe, coff);
+    fw.store(0, coff, w);
+    // after a step_all both group widths equal the shared width (:436-437): that is what the epsilon terms use
+    measure_chain<R, NR, NC, true, true, NT, NTM>(ma, c, x, fmean, fobs, fcov, ffac, nullptr,
+                                                  [&](R &w_real, R &w_cplx) { w_real = w_cplx = w; }, bad_pivot);
+  }
+  if ((threadIdx.x & 63) == 0 && wave_accepted) {
+    unsigned long long *slot = a.accept_slots + (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    *slot += (unsigned long long)wave_accepted;
+  }
+  const unsigned int bits = (bad_energy ? ST_NONFINITE_ENERGY : 0u) | (bad_width ? ST_BAD_WIDTH : 0u) | (bad_pivot ? ST_BAD_PIVOT : 0u);
+  if (bits) atomicOr(a.status, bits);
 }
 
 // Refresh the per-chain proposal factors from the per-chain covariance: factor = chol(C_r), chol(conj(K)).

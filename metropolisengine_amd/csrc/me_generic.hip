@@ -1,5 +1,6 @@
 // Dimension-independent kernels: broadcast fill and the ensemble (pooled) moment reduction.
 #include "me_internal.h"
+#include "me_per_device.h"
 
 namespace me {
 namespace {
@@ -27,20 +28,24 @@ __device__ __forceinline__ void pair_of(int p, int &i, int &j) {
   j = p - i * (i + 1) / 2;
 }
 
-constexpr int kTileChains = 64;   // chains staged per LDS tile
-constexpr int kTilePitch = 65;    // +1 pad: threads walk different rows at the same column
-constexpr int kMaxEntries = 12;   // moment entries per thread -> up to 3072 entries per engine
+constexpr int kMaxEntries = 12;   // moment entries per thread and pass -> 3072 entries per pass
 
-// k_pool_reduce: S = sum over chains of [1, x, x x^T (lower), |x_r|, |z_c|] in fp64, in two launches.
-// Stage 1: a block stages a tile of 64 chains x (D + nr + nc) augmented rows in LDS; every thread owns a fixed set of
-// entries and walks the tile's 64 columns for each (in the device dtype within a tile, fp64 across tiles); per-block
-// partial sums are written to partials[block][entry].  Stage 2 (k_pool_finish) sums the partials per entry and writes
-// the result in the public order (me_pooled_moments).  No atomics: a thousand blocks adding to the same ~200 words
-// with fp64 atomics serialise at the memory side (measured: the one-launch atomic version was 2x slower).
-template <typename R>
-__global__ void __launch_bounds__(kBlockThreads) k_pool_reduce(const R *x, long long n, int nr, int nc, double *partials) {
+// k_pool_reduce: S = sum over chains of [1, x, x x^T (lower), |x_r|, |z_c|] in fp64, in two stages.
+// Stage 1: a block stages a tile of TILE chains x (D + nr + nc) augmented rows in LDS (pitch TILE + 1: threads walk
+// different rows at the same column); every thread owns a fixed set of entries and walks the tile's columns for each (in
+// the device dtype within a tile, fp64 across tiles); per-block partial sums are written to partials[block][entry].
+// One pass covers kMaxEntries x 256 = 3072 entries starting at entry_base: parameter spaces with more entries than that
+// (beyond ~75 real degrees of freedom, up to the 42 k entries of 290 parameters) take several passes, each staging the
+// tile again (x is read once per pass -- this reduction runs once per adaptation, not per step).  TILE is 64 where the
+// staged tile fits the LDS, 32 or 16 for the largest spaces.
+// Stage 2 (k_pool_finish) sums the partials per entry and writes the result in the public order (me_pooled_moments).
+// No atomics: a thousand blocks adding to the same ~200 words with fp64 atomics serialise at the memory side (measured:
+// the one-launch atomic version was 2x slower).
+template <typename R, int TILE>
+__global__ void __launch_bounds__(kBlockThreads) k_pool_reduce(const R *x, long long n, int nr, int nc, int entry_base, double *partials) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R *tile = reinterpret_cast<R *>(smem_raw);
+  constexpr int kTilePitch = TILE + 1;
   const int d = nr + 2 * nc;
   const int n_aug = d + nr + nc;
   const int n_pair = d * (d + 1) / 2;
@@ -53,7 +58,7 @@ __global__ void __launch_bounds__(kBlockThreads) k_pool_reduce(const R *x, long 
   double acc[kMaxEntries];
 #pragma unroll
   for (int k = 0; k < kMaxEntries; ++k) {
-    const int e = tid + k * kBlockThreads;
+    const int e = entry_base + tid + k * kBlockThreads;
     acc[k] = 0.0;
     row_i[k] = row_j[k] = -1;
     active[k] = e < n_entries;
@@ -65,13 +70,13 @@ __global__ void __launch_bounds__(kBlockThreads) k_pool_reduce(const R *x, long 
     }
   }
 
-  const long long n_tiles = (n + kTileChains - 1) / kTileChains;
+  const long long n_tiles = (n + TILE - 1) / TILE;
   for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const long long base = t * kTileChains;
-    const int valid = (int)((n - base) < kTileChains ? (n - base) : kTileChains);
-    // stage: thread (r, col) pattern; 256 threads cover 4 rows x 64 columns per pass
-    for (int r = tid / kTileChains; r < n_aug; r += kBlockThreads / kTileChains) {
-      const int col = tid % kTileChains;
+    const long long base = t * TILE;
+    const int valid = (int)((n - base) < TILE ? (n - base) : TILE);
+    // stage: thread (r, col) pattern; 256 threads cover 256 / TILE rows x TILE columns per pass
+    for (int r = tid / TILE; r < n_aug; r += kBlockThreads / TILE) {
+      const int col = tid % TILE;
       R v = 0;
       if (col < valid) {
         const long long c = base + col;
@@ -96,13 +101,13 @@ __global__ void __launch_bounds__(kBlockThreads) k_pool_reduce(const R *x, long 
       } else if (row_j[k] < 0) {
         const R *ri = tile + row_i[k] * kTilePitch;
         R s = 0;
-        for (int col = 0; col < kTileChains; ++col) s += ri[col];
+        for (int col = 0; col < TILE; ++col) s += ri[col];
         acc[k] += (double)s;
       } else {
         const R *ri = tile + row_i[k] * kTilePitch;
         const R *rj = tile + row_j[k] * kTilePitch;
         R s = 0;
-        for (int col = 0; col < kTileChains; ++col) s += ri[col] * rj[col];
+        for (int col = 0; col < TILE; ++col) s += ri[col] * rj[col];
         acc[k] += (double)s;
       }
     }
@@ -110,7 +115,7 @@ __global__ void __launch_bounds__(kBlockThreads) k_pool_reduce(const R *x, long 
   }
 #pragma unroll
   for (int k = 0; k < kMaxEntries; ++k)
-    if (active[k]) partials[(long long)blockIdx.x * n_entries + tid + k * kBlockThreads] = acc[k];
+    if (active[k]) partials[(long long)blockIdx.x * n_entries + entry_base + tid + k * kBlockThreads] = acc[k];
 }
 
 // Stage 2: 64 entries x 16 block-slices per workgroup; a thread sums every 16th block's partial of its entry (consecutive
@@ -270,14 +275,19 @@ hipError_t launch_sum_slots(const unsigned long long *slots, long long n_slots, 
   return hipGetLastError();
 }
 
-// whether launch_pool_reduce can handle these dimensions (entry count and the LDS tile of the first stage)
-bool pool_reduce_supported(int nr, int nc, int dtype) {
-  const int d = nr + 2 * nc;
-  const int n_aug = d + nr + nc;
-  const long long n_entries = 1 + n_aug + (long long)d * (d + 1) / 2;
+// chains per staged tile: the widest of 64 / 32 / 16 whose (D + nr + nc) rows fit the LDS of a workgroup; 0 = none does
+constexpr size_t kPoolLdsLimit = 160 * 1024;
+int pool_tile_chains(int nr, int nc, int dtype) {
+  const int n_aug = nr + 2 * nc + nr + nc;
   const size_t elem = dtype == ME_F32 ? sizeof(float) : sizeof(double);
-  return n_entries <= (long long)kMaxEntries * kBlockThreads && (size_t)n_aug * kTilePitch * elem <= 160 * 1024;
+  for (int tile : {64, 32, 16})
+    if ((size_t)n_aug * (size_t)(tile + 1) * elem <= kPoolLdsLimit) return tile;
+  return 0;
 }
+
+// whether launch_pool_reduce can handle these dimensions (the LDS tile of the first stage; the entry count no longer
+// matters: stage 1 runs in passes of 3072 entries)
+bool pool_reduce_supported(int nr, int nc, int dtype) { return pool_tile_chains(nr, nc, dtype) != 0; }
 
 int pool_reduce_blocks(long long n, int nr, int nc) {
   const int d = nr + 2 * nc;
@@ -285,9 +295,37 @@ int pool_reduce_blocks(long long n, int nr, int nc) {
   long long cap = (32ll << 20) / (8 * n_entries);   // at most 32 MiB of partials
   if (cap > 1024) cap = 1024;
   if (cap < 64) cap = 64;
-  const long long tiles = (n + kTileChains - 1) / kTileChains;
+  const long long tiles = (n + 63) / 64;
   return (int)(tiles < cap ? (tiles < 1 ? 1 : tiles) : cap);
 }
+
+namespace {
+template <typename R, int TILE>
+hipError_t launch_pool_stage1(const void *x, long long n, int nr, int nc, int n_entries, int blocks, double *partials, hipStream_t stream) {
+  const size_t lds = (size_t)(nr + 2 * nc + nr + nc) * (size_t)(TILE + 1) * sizeof(R);
+  if (lds > 64 * 1024) {
+    static PerDevice<hipError_t> attr;
+    int device = 0;
+    if (hipError_t rc = hipGetDevice(&device); rc != hipSuccess) return rc;
+    const hipError_t rc = attr.get(device, [] {
+      return hipFuncSetAttribute((const void *)k_pool_reduce<R, TILE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPoolLdsLimit);
+    });
+    if (rc != hipSuccess) return rc;
+  }
+  for (int base = 0; base < n_entries; base += kMaxEntries * kBlockThreads)
+    hipLaunchKernelGGL((k_pool_reduce<R, TILE>), dim3((unsigned)blocks), dim3(kBlockThreads), lds, stream, (const R *)x, n, nr, nc, base, partials);
+  return hipGetLastError();
+}
+template <typename R>
+hipError_t launch_pool_stage1_tile(int tile, const void *x, long long n, int nr, int nc, int n_entries, int blocks, double *partials, hipStream_t stream) {
+  switch (tile) {
+    case 64: return launch_pool_stage1<R, 64>(x, n, nr, nc, n_entries, blocks, partials, stream);
+    case 32: return launch_pool_stage1<R, 32>(x, n, nr, nc, n_entries, blocks, partials, stream);
+    case 16: return launch_pool_stage1<R, 16>(x, n, nr, nc, n_entries, blocks, partials, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+}  // namespace
 
 hipError_t launch_pool_reduce(const void *x, long long n, int nr, int nc, int dtype, const unsigned long long *slots,
                               long long n_slots, double proposed, double *partials, double *out_device,
@@ -296,31 +334,13 @@ hipError_t launch_pool_reduce(const void *x, long long n, int nr, int nc, int dt
   const int d = nr + 2 * nc;
   const int n_aug = d + nr + nc;
   const int n_entries = 1 + n_aug + d * (d + 1) / 2;
-  if (n_entries > kMaxEntries * kBlockThreads) return hipErrorInvalidValue;
-  const size_t elem = dtype == ME_F32 ? sizeof(float) : sizeof(double);
-  const size_t lds = (size_t)n_aug * kTilePitch * elem;
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  const int tile = pool_tile_chains(nr, nc, dtype);
+  if (!stage1 && tile == 0) return hipErrorInvalidValue;
   const int blocks = pool_reduce_blocks(n, nr, nc);
   hipError_t err;
-  if (stage1) {
-    err = stage1(x, n, partials, blocks, stream);
-    if (err != hipSuccess) return err;
-  } else if (dtype == ME_F32) {
-    if (lds > 64 * 1024) {
-      err = hipFuncSetAttribute((const void *)k_pool_reduce<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (err != hipSuccess) return err;
-    }
-    hipLaunchKernelGGL(k_pool_reduce<float>, dim3((unsigned)blocks), dim3(kBlockThreads), lds, stream, (const float *)x, n,
-                       nr, nc, partials);
-  } else {
-    if (lds > 64 * 1024) {
-      err = hipFuncSetAttribute((const void *)k_pool_reduce<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (err != hipSuccess) return err;
-    }
-    hipLaunchKernelGGL(k_pool_reduce<double>, dim3((unsigned)blocks), dim3(kBlockThreads), lds, stream, (const double *)x,
-                       n, nr, nc, partials);
-  }
-  err = hipGetLastError();
+  if (stage1) err = stage1(x, n, partials, blocks, stream);
+  else if (dtype == ME_F32) err = launch_pool_stage1_tile<float>(tile, x, n, nr, nc, n_entries, blocks, partials, stream);
+  else err = launch_pool_stage1_tile<double>(tile, x, n, nr, nc, n_entries, blocks, partials, stream);
   if (err != hipSuccess) return err;
   hipLaunchKernelGGL(k_pool_finish, dim3((unsigned)((n_entries + 63) / 64 + 1)), dim3(kFinishThreads), 0, stream,
                      (const double *)partials, blocks, nr, nc, slots, n_slots, proposed, out_device);

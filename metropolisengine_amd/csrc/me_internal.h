@@ -120,6 +120,9 @@ struct KernelSet {
   // per_chain_cov with the packed matrices STREAMED (more than 160 entries, pure real spaces): the covariance and factor
   // fields are only kept for ME_COV_REFERENCE (or the tracking flag), are walked with 64-bit pointers and may pass 4 GiB
   bool streams_packed;
+  // optional: n_sweeps x step_all + measure in ONE launch (k_cycle); nullptr or hipErrorNotSupported: me_cycle issues the
+  // step launch and the measure launch instead (same results)
+  hipError_t (*cycle)(const StepLaunch &, const MeasureLaunch &, hipStream_t);
 };
 
 void register_kernel_set(const KernelSet *set);

@@ -381,7 +381,7 @@ hipError_t init_energy(const EnergyLaunch &l, hipStream_t stream) {
 }
 
 template <typename R>
-hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
+MeasureArgs<R> typed_measure(const MeasureLaunch &l) {
   MeasureArgs<R> a;
   a.x = (const R *)l.x;
   a.width = (const R *)l.width;
@@ -398,6 +398,53 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
   a.update_cov = l.update_cov;
   a.split_widths = l.split_widths;
   a.write_factor = l.write_factor;
+  return a;
+}
+
+// n_sweeps x step_all + measure in one launch (k_cycle, me_device.h) for the kernel sets whose packed matrix lives in
+// registers; anything else -- group steps, injected streams, a shared factor, engines that keep no per-chain covariance,
+// the matrix-core kernels of the dense 64-parameter form -- answers hipErrorNotSupported and me_cycle issues two launches.
+#ifndef ME_CYCLE
+#define ME_CYCLE (ME_PER_CHAIN == 1)
+#endif
+template <typename R>
+hipError_t cycle(const StepLaunch &l, const MeasureLaunch &ml, hipStream_t stream) {
+#if ME_CYCLE
+  constexpr int P = NR * (NR + 1) / 2 + NC * NC;
+  if constexpr (P <= kMaxPackedInRegisters) {
+    if (l.group != GROUP_ALL || l.inj_normals || !ml.cov || !ml.factor) return hipErrorNotSupported;
+    if (l.cov_kind != CK_IDENTITY && l.cov_kind != CK_PER_CHAIN) return hipErrorNotSupported;
+    return with_energy<R>(l.energy_kind, l.coef_host, l.n_coef, l.coef_device, [&](const auto &en) -> hipError_t {
+      using Energy = std::decay_t<decltype(en)>;
+#if ME_DENSE && !defined(ME_USER_SOURCE)
+      if constexpr (NR == 64 && NC == 0 && std::is_same<Energy, EnergyDense<R, 64, 0>>::value) return hipErrorNotSupported;
+#endif
+      const StepArgs<R> a = typed<R>(l);
+      const MeasureArgs<R> ma = typed_measure<R>(ml);
+      // cache policy by size, as in k_step / k_measure: everything the launch touches per chain
+      constexpr long long mean_bytes = (long long)sizeof(R) * (2 * D + (2 * NR + NC));
+      constexpr long long all_bytes = mean_bytes + (long long)sizeof(R) * (2 + 2 * P);
+      const bool nt = all_bytes * l.n > cache_budget_bytes(), ntm = mean_bytes * l.n > cache_budget_bytes();
+      const int threads = l.n_sweeps >= kFusedSweepsThreshold ? kFusedStepThreads : kStepThreads;
+      const dim3 grid(grid_for(l.n, l.grid_blocks, threads)), block(threads);
+      auto launch = [&](auto ck) {
+        constexpr int CK = decltype(ck)::value;
+        if (ntm) hipLaunchKernelGGL((k_cycle<R, NR, NC, Energy, CK, true, true>), grid, block, 0, stream, a, ma, en);
+        else if (nt) hipLaunchKernelGGL((k_cycle<R, NR, NC, Energy, CK, true, false>), grid, block, 0, stream, a, ma, en);
+        else hipLaunchKernelGGL((k_cycle<R, NR, NC, Energy, CK, false, false>), grid, block, 0, stream, a, ma, en);
+      };
+      if (l.cov_kind == CK_PER_CHAIN) launch(std::integral_constant<int, CK_PER_CHAIN>{});
+      else launch(std::integral_constant<int, CK_IDENTITY>{});
+      return hipGetLastError();
+    });
+  }
+#endif
+  return hipErrorNotSupported;
+}
+
+template <typename R>
+hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
+  const MeasureArgs<R> a = typed_measure<R>(l);
   // small packed matrices: one fused launch; large ones: streaming update, then the factor kernel (see k_measure)
   constexpr int P = NR * (NR + 1) / 2 + NC * NC;
   constexpr bool kFused = ME_PER_CHAIN == 1 && P <= ME_MEASURE_FUSED_MAX_P;
@@ -492,12 +539,12 @@ constexpr bool kHasUserReject = false;
 #if ME_ONLY_DTYPE != 64
 const KernelSet kSetF32 = {ME_SET_NAME, ME_F32, NR, NC, ME_PER_CHAIN != 0, (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0), has_energy, energy_terms, step<float>,
                            (NC > 0 && ME_PER_CHAIN == 1) ? magphase<float> : nullptr, measure<float>, init_energy<float>,
-                           ME_PREPARE_MATRIX_F32, kHasUserReject, ME_PER_CHAIN == 2};
+                           ME_PREPARE_MATRIX_F32, kHasUserReject, ME_PER_CHAIN == 2, cycle<float>};
 #endif
 #if ME_ONLY_DTYPE != 32
 const KernelSet kSetF64 = {ME_SET_NAME, ME_F64, NR, NC, ME_PER_CHAIN != 0, (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0), has_energy, energy_terms, step<double>,
                            (NC > 0 && ME_PER_CHAIN == 1) ? magphase<double> : nullptr, measure<double>, init_energy<double>,
-                           ME_PREPARE_MATRIX_F64, kHasUserReject, ME_PER_CHAIN == 2};
+                           ME_PREPARE_MATRIX_F64, kHasUserReject, ME_PER_CHAIN == 2, cycle<double>};
 #endif
 
 struct Registrar {

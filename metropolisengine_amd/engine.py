@@ -269,6 +269,18 @@ class MetropolisEngine:
         """Update running means, covariances (once measure_step_counter > 50) and observables (:342-427)."""
         self._check(self._lib.me_measure(self._handle))
 
+    def cycle(self, n_sweeps=1):
+        """``n_sweeps`` x ``step_all()`` followed by ``measure()`` -- one iteration of the reference's driver loop
+        (README.md:41-44) -- as ONE kernel launch where the engine has a fused kernel (``me_cycle``); same results as
+        ``step_all(n_sweeps); measure()``."""
+        self._check(self._lib.me_cycle(self._handle, int(n_sweeps)))
+
+    def fused_cycles(self):
+        """How many :meth:`cycle` calls ran as one launch (the others fell back to a step and a measure launch)."""
+        count = ctypes.c_uint64()
+        self._check(self._lib.me_cycle_stats(self._handle, ctypes.byref(count)))
+        return count.value
+
     measure_real_system = measure                                                        # :57
     measure_complex_system = measure                                                     # :47
 

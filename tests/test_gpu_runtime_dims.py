@@ -132,6 +132,41 @@ def test_dense_energy_and_shared_factor_at_120_real(shape):
     assert np.all(np.abs(eng._get(0)[:, 0]) < 1.0)
 
 
+@pytest.mark.parametrize("nr,nc,dtype", [(96, 0, "f64"), (120, 0, "f64"), (120, 0, "f32"), (60, 25, "f64"), (200, 0, "f64")])
+def test_pooled_moments_and_adapt_pooled_shape_beyond_75_degrees_of_freedom(nr, nc, dtype):
+    """me_pooled_moments used to stop at 3 072 moment entries (about 75 real degrees of freedom): stage 1 of the reduction
+    now runs in passes of 3 072 entries (tiles of 64 / 32 / 16 chains by LDS size), so every engine that accepts
+    cov_mode="pooled" can obtain its shared shape in-library.  Sums against numpy on the engine's own state."""
+    from metropolisengine_amd import distributed
+    n = 1000 + 37
+    d = nr + 2 * nc
+    a_r = np.linspace(0.5, 2.0, nr)
+    a_c = np.linspace(0.7, 1.5, nc)
+    pure_real = nc == 0
+    eng = me.MetropolisEngine(me.DiagQuadratic(a_r, a_c), None, list(np.linspace(-0.2, 0.2, nr)),
+                              (list(0.1 * np.exp(1j * np.arange(nc))) if nc else None), temp=1.0, n_chains=n, seed=4, dtype=dtype,
+                              sampling_width=0.1, cov_mode="pooled" if pure_real else "fixed")
+    eng.step_all(40)
+    x = eng._get(0)
+    got = eng.pooled_moments()
+    assert got.shape == (distributed.moments_size(nr, nc),)
+    tol = dict(rtol=1e-12, atol=1e-9) if dtype == "f64" else dict(rtol=2e-5, atol=2e-3)
+    assert got[0] == n
+    assert np.allclose(got[1:1 + d], x.sum(axis=0), **tol)
+    second = x.T @ x
+    assert np.allclose(got[1 + d:1 + d + d * (d + 1) // 2], second[np.tril_indices(d)], **tol)
+    z = x[:, nr:nr + nc] + 1j * x[:, nr + nc:]
+    obs = np.concatenate((np.abs(x[:, :nr]).sum(axis=0), np.abs(z).sum(axis=0), (x[:, :nr] ** 2).sum(axis=0)))
+    assert np.allclose(got[1 + d + d * (d + 1) // 2:-2], obs, **tol)
+    assert (got[-2], got[-1]) == tuple(float(v) for v in eng.accept_stats())
+    if pure_real:
+        stats = distributed.adapt_pooled_shape(eng, jitter=1e-6)      # pooled covariance -> Cholesky -> shared factor
+        assert np.allclose(stats["covariance"], np.cov(x.T, bias=True), **tol)
+        assert np.allclose(eng.shared_factor(), distributed.pooled_factor(stats["covariance"], nr, 0, jitter=1e-6))
+        eng.step_all(3)                                               # and the engine steps with it
+        assert 0.0 < eng.acceptance_rate() < 1.0
+
+
 def test_unsupported_combinations_fail_loudly():
     with pytest.raises(NotImplementedError, match="identity proposal shape"):
         me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 120, None, temp=1.0, n_chains=8)      # cov_mode="reference"
@@ -140,6 +175,14 @@ def test_unsupported_combinations_fail_loudly():
                             cov_mode="fixed")                                                  # x' would not fit in LDS
     with pytest.raises(NotImplementedError):
         me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 100, [0j] * 10, temp=1.0, n_chains=8, cov_mode="pooled")
+    # a non-identity initial covariance makes the engine start with a SHARED factor: refused at creation (not at the first
+    # step) where the runtime set has no shared-factor form -- complex parameters, or 2 x D x 64 values beyond the LDS
+    with pytest.raises(NotImplementedError, match="identity proposal shape only"):
+        me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 100, [0j] * 10, covariance_matrix_real=2.0 * np.identity(100),
+                            temp=1.0, n_chains=8, cov_mode="fixed")
+    with pytest.raises(NotImplementedError, match="LDS"):
+        me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 200, None, covariance_matrix_real=2.0 * np.identity(200),
+                            temp=1.0, n_chains=8, cov_mode="fixed", dtype="f64")
     eng = me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 120, None, temp=1.0, n_chains=8, cov_mode="fixed")
     with pytest.raises(NotImplementedError):
         eng.covariance_matrix_real
