@@ -27,7 +27,7 @@ __device__ R me_user_energy(const R *x, const R *coef) {
 #pragma unroll
   for (int j = 0; j < ME_NC; ++j) {
     const R q = wavenumber * (R(j) - R(ME_NC - 1) * R(0.5));
-    const R mod2 = x[ME_NR + j] * x[ME_NR + j] + x[ME_NR + ME_NC + j] * x[ME_NR + ME_NC + j];
+    const R mod2 = me_fma(x[ME_NR + j], x[ME_NR + j], x[ME_NR + ME_NC + j] * x[ME_NR + ME_NC + j]);
     field += (gamma + q * q * amp) * mod2;
     tot += mod2;
   }

@@ -42,4 +42,10 @@
 #ifndef METROPOLIS_USER_ENERGY_H
 #define METROPOLIS_USER_ENERGY_H
 #include <hip/hip_runtime.h>
+/* One explicit fused multiply-add, a * b + c.  hipcc fuses multiply-adds by itself, but in a sum of TWO products
+ * (a * b + c * d, e.g. |z|^2 = re * re + im * im) it may fuse either one, and which one can depend on the kernel the
+ * function is inlined into.  Energies whose values must be bit-identical in every kernel of the engine (me_step against
+ * me_cycle, float32) spell such sums me_fma(a, b, c * d). */
+__device__ __forceinline__ float me_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double me_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 #endif

@@ -54,6 +54,9 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 #ifndef ME_DENSE64_F64_RNG_UNROLL
 #define ME_DENSE64_F64_RNG_UNROLL 2     // 2 blocks (4 Box-Muller pairs) per iteration: -2.5 % on the fused sweep against 1; 4: no further gain
 #endif
+#ifndef ME_DENSE64_F64_NT
+#define ME_DENSE64_F64_NT 0             // experiment: bit 0 = state loads non-temporal, bit 1 = state stores non-temporal
+#endif
 constexpr int kDense64F64Threads = 512;                  // 8 waves, two per SIMD
 constexpr int kDense64F64Frags = 40;                     // (mb, ks) pairs with 4 ks < 16 (mb + 1)
 constexpr int kDense64F64ImageDoubles = kDense64F64Frags * 64;
@@ -176,7 +179,7 @@ __global__ void __launch_bounds__(kDense64F64Threads, 2)
     const long long c = chain_of(tile);
     const unsigned int xoff = state_off(fx, c);
 #pragma unroll
-    for (int i = 0; i < H; ++i) x[i] = fx.load(i, xoff);
+    for (int i = 0; i < H; ++i) x[i] = (ME_DENSE64_F64_NT & 1) ? fx.load_nt(i, xoff) : fx.load(i, xoff);
     e = fe.load(0, (unsigned int)c * 8u);
     w = fw.load(0, (unsigned int)c * 8u);
   }
@@ -208,7 +211,7 @@ __global__ void __launch_bounds__(kDense64F64Threads, 2)
         const long long cn = chain_of(next);
         const unsigned int noff = state_off(fxt, cn);
 #pragma unroll
-        for (int i = 0; i < H; ++i) xn[i] = fxt.load(i, noff);
+        for (int i = 0; i < H; ++i) xn[i] = (ME_DENSE64_F64_NT & 1) ? fxt.load_nt(i, noff) : fxt.load(i, noff);
         en = fe.load(0, (unsigned int)cn * 8u);
         wn = fw.load(0, (unsigned int)cn * 8u);
       }
@@ -310,7 +313,10 @@ __global__ void __launch_bounds__(kDense64F64Threads, 2)
     if (live) {
       const unsigned int xoff = state_off(fxt, c);
 #pragma unroll
-      for (int i = 0; i < H; ++i) fxt.store(i, xoff, x[i]);
+      for (int i = 0; i < H; ++i) {
+        if constexpr ((ME_DENSE64_F64_NT & 2) != 0) fxt.store_nt(i, xoff, x[i]);
+        else fxt.store(i, xoff, x[i]);
+      }
       if (half == 0) {
         fe.store(0, coff, e);
         fw.store(0, coff, w);

@@ -49,6 +49,13 @@ __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
 }
 
 // ------------------------------------------------------------------------------------------------ numerics
+// One explicit fused multiply-add.  hipcc contracts a * b + c by itself (-ffp-contract=fast), but for a * b + c * d it may
+// fuse either product, and which one depends on the code around the expression -- so the same source line can round
+// differently in two kernels.  Wherever a result must be BITWISE the same in k_measure and k_cycle (both inline
+// measure_chain) or in pass 1 and pass 2 of the runtime-dimension kernels, sums of two products are spelled with fma_.
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 template <typename R>
 struct Num;
 
@@ -363,9 +370,9 @@ struct EnergyLandau {  // k(1-x)^2 + k(1-y)^2 + x y (alpha |c|^2 + beta |c|^4)  
   R k, alpha, beta;
   __device__ __forceinline__ R operator()(const R (&x)[D]) const {
     static_assert(NR == 2 && NC == 1, "Landau toy is 2 real + 1 complex");
-    const R a2 = x[2] * x[2] + x[3] * x[3];
+    const R a2 = fma_(x[2], x[2], x[3] * x[3]);
     const R ox = R(1) - x[0], oy = R(1) - x[1];
-    return k * ox * ox + k * oy * oy + x[0] * x[1] * (alpha * a2 + beta * a2 * a2);
+    return fma_(x[0] * x[1], fma_(beta * a2, a2, alpha * a2), fma_(k * ox, ox, k * oy * oy));
   }
 };
 
@@ -385,7 +392,7 @@ struct EnergyCylinder {  // cylinder-style surrogate, see oracle/energies.py:cyl
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const R q = wavenumber * (R(j) - R(NC - 1) * R(0.5));
-      const R mod2 = x[NR + j] * x[NR + j] + x[NR + NC + j] * x[NR + NC + j];
+      const R mod2 = fma_(x[NR + j], x[NR + j], x[NR + NC + j] * x[NR + NC + j]);
       field += (gamma + q * q * amp) * mod2;
       tot += mod2;
     }
@@ -405,11 +412,11 @@ struct EnergyLandauTerms {
   __device__ __forceinline__ R term(int t, const R (&x)[D]) const {
     static_assert(NR == 2 && NC == 1, "Landau toy is 2 real + 1 complex");
     if (t == 0) {
-      const R a2 = x[2] * x[2] + x[3] * x[3];
-      return x[0] * x[1] * (alpha * a2 + beta * a2 * a2);
+      const R a2 = fma_(x[2], x[2], x[3] * x[3]);
+      return x[0] * x[1] * fma_(beta * a2, a2, alpha * a2);
     }
     const R ox = R(1) - x[0], oy = R(1) - x[1];
-    return k * ox * ox + k * oy * oy;
+    return fma_(k * ox, ox, k * oy * oy);
   }
 };
 
@@ -958,7 +965,7 @@ __device__ __forceinline__ void cholesky_packed(R (&m)[NR * (NR + 1) / 2 + NC * 
     for (int j = 0; j < NR; ++j) {
       R s = m[tri(j, j)];
 #pragma unroll
-      for (int k = 0; k < j; ++k) s -= m[tri(j, k)] * m[tri(j, k)];
+      for (int k = 0; k < j; ++k) s = fma_(-m[tri(j, k)], m[tri(j, k)], s);
       if (!(s > R(0))) { bad_pivot = true; s = R(1e-30); }
       const R dg = N_::sqrt_(s);
       const R inv = R(1) / dg;
@@ -967,7 +974,7 @@ __device__ __forceinline__ void cholesky_packed(R (&m)[NR * (NR + 1) / 2 + NC * 
       for (int i = j + 1; i < NR; ++i) {
         R t = m[tri(i, j)];
 #pragma unroll
-        for (int k = 0; k < j; ++k) t -= m[tri(i, k)] * m[tri(j, k)];
+        for (int k = 0; k < j; ++k) t = fma_(-m[tri(i, k)], m[tri(j, k)], t);
         m[tri(i, j)] = t * inv;
       }
     }
@@ -976,7 +983,7 @@ __device__ __forceinline__ void cholesky_packed(R (&m)[NR * (NR + 1) / 2 + NC * 
     for (int j = 0; j < NC; ++j) {
       R s = m[cdiag(PR, j)];
 #pragma unroll
-      for (int k = 0; k < j; ++k) s -= m[cre(PR, j, k)] * m[cre(PR, j, k)] + m[cim(PR, j, k)] * m[cim(PR, j, k)];
+      for (int k = 0; k < j; ++k) s = fma_(-m[cim(PR, j, k)], m[cim(PR, j, k)], fma_(-m[cre(PR, j, k)], m[cre(PR, j, k)], s));
       if (!(s > R(0))) { bad_pivot = true; s = R(1e-30); }
       const R dg = N_::sqrt_(s);
       const R inv = R(1) / dg;
@@ -989,8 +996,8 @@ __device__ __forceinline__ void cholesky_packed(R (&m)[NR * (NR + 1) / 2 + NC * 
           // t -= L_ik conj(L_jk)
           const R ar = m[cre(PR, i, k)], ai2 = m[cim(PR, i, k)];
           const R br = m[cre(PR, j, k)], bi2 = m[cim(PR, j, k)];
-          tr -= ar * br + ai2 * bi2;
-          ti -= ai2 * br - ar * bi2;
+          tr = fma_(-ai2, bi2, fma_(-ar, br, tr));
+          ti = fma_(ar, bi2, fma_(-ai2, br, ti));
         }
         m[cre(PR, i, j)] = tr * inv;
         m[cim(PR, i, j)] = ti * inv;
@@ -1038,7 +1045,7 @@ __device__ __forceinline__ void measure_chain(const MeasureArgs<R> &a, long long
     for (int d = 0; d < D; ++d) {
       if constexpr (STREAM) s_delta[d][threadIdx.x] = x[d] - mu[d];   // parked in LDS, see the streaming path below
       else delta[d] = x[d] - mu[d];
-      packed_store<NTM>(fmean, d, coff, mu[d] * a.keep + x[d] * a.inv_i);   // :404-410
+      packed_store<NTM>(fmean, d, coff, fma_(x[d], a.inv_i, mu[d] * a.keep));   // :404-410
     }
   }
   // observables [|x_r|, |z_c|, x_r^2] and their running mean (:458-463, :412-414), in batches of kBatch
@@ -1055,9 +1062,9 @@ __device__ __forceinline__ void measure_chain(const MeasureArgs<R> &a, long long
       if (k < NOBS) {
         R o;
         if (k < NR) o = N_::abs_(x[k]);
-        else if (k < NR + NC) o = N_::sqrt_(x[k] * x[k] + x[k + NC] * x[k + NC]);
+        else if (k < NR + NC) o = N_::sqrt_(fma_(x[k], x[k], x[k + NC] * x[k + NC]));
         else o = x[k - NR - NC] * x[k - NR - NC];
-        packed_store<NTM>(fobs, k, coff, m[u] * a.keep + o * a.inv_i);
+        packed_store<NTM>(fobs, k, coff, fma_(o, a.inv_i, m[u] * a.keep));
       }
     }
   }
@@ -1066,8 +1073,9 @@ __device__ __forceinline__ void measure_chain(const MeasureArgs<R> &a, long long
       // :418, :425 -- each block uses its own group's width; they coincide unless group steps made them differ
       R w_real, w_cplx;
       widths(w_real, w_cplx);
-      const R eps = w_real * w_real * a.inv_i;
-      const R eps_c = w_cplx * w_cplx * a.inv_i;
+      // the epsilon term sigma^2 / i (:418, :425) goes into the diagonal through an explicit fma: left as `v += w * w * inv_i`
+      // the compiler may or may not fuse the product into the add, kernel by kernel
+      const R w2_real = w_real * w_real, w2_cplx = w_cplx * w_cplx;
       if constexpr (STREAM) {
         // delta is parked in LDS (lane-linear, conflict-free) so that the walk over the packed entries can be a
         // ROLLED loop: unrolled, 2 080 entries are ~100 KB of code and the kernel becomes instruction-fetch bound.
@@ -1085,7 +1093,7 @@ __device__ __forceinline__ void measure_chain(const MeasureArgs<R> &a, long long
 #pragma unroll
             for (int u = 0; u < 16; ++u) v[u] = p[u * ts];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) p[u * ts] = v[u] * a.cov_keep + di * s_delta[j + u][threadIdx.x] * a.inv_i;
+            for (int u = 0; u < 16; ++u) p[u * ts] = fma_(di * s_delta[j + u][threadIdx.x], a.inv_i, v[u] * a.cov_keep);
             p += 16 * ts;
           }
           for (; j + 4 <= i; j += 4) {
@@ -1093,14 +1101,14 @@ __device__ __forceinline__ void measure_chain(const MeasureArgs<R> &a, long long
 #pragma unroll
             for (int u = 0; u < 4; ++u) v[u] = p[u * ts];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) p[u * ts] = v[u] * a.cov_keep + di * s_delta[j + u][threadIdx.x] * a.inv_i;
+            for (int u = 0; u < 4; ++u) p[u * ts] = fma_(di * s_delta[j + u][threadIdx.x], a.inv_i, v[u] * a.cov_keep);
             p += 4 * ts;
           }
           for (; j < i; ++j) {
-            *p = *p * a.cov_keep + di * s_delta[j][threadIdx.x] * a.inv_i;
+            *p = fma_(di * s_delta[j][threadIdx.x], a.inv_i, *p * a.cov_keep);
             p += ts;
           }
-          *p = *p * a.cov_keep + di * di * a.inv_i + eps;
+          *p = fma_(w2_real, a.inv_i, fma_(di * di, a.inv_i, *p * a.cov_keep));
           p += ts;
         }
         for (int i = 0; i < NC; ++i) {
@@ -1113,19 +1121,19 @@ __device__ __forceinline__ void measure_chain(const MeasureArgs<R> &a, long long
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
               const R aj = s_delta[NR + j + u][threadIdx.x], bj = s_delta[NR + NC + j + u][threadIdx.x];
-              p[(2 * u) * ts] = v[2 * u] * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
-              p[(2 * u + 1) * ts] = v[2 * u + 1] * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
+              p[(2 * u) * ts] = fma_(fma_(ai, aj, bi * bj), a.inv_i, v[2 * u] * a.cov_keep);
+              p[(2 * u + 1) * ts] = fma_(fma_(bi, aj, -(ai * bj)), a.inv_i, v[2 * u + 1] * a.cov_keep);
             }
             p += 16 * ts;
           }
           for (; j < i; ++j) {
             const R aj = s_delta[NR + j][threadIdx.x], bj = s_delta[NR + NC + j][threadIdx.x];
             const R re = p[0], im = p[ts];
-            p[0] = re * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
-            p[ts] = im * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
+            p[0] = fma_(fma_(ai, aj, bi * bj), a.inv_i, re * a.cov_keep);
+            p[ts] = fma_(fma_(bi, aj, -(ai * bj)), a.inv_i, im * a.cov_keep);
             p += 2 * ts;
           }
-          *p = *p * a.cov_keep + (ai * ai + bi * bi) * a.inv_i + eps_c;
+          *p = fma_(w2_cplx, a.inv_i, fma_(fma_(ai, ai, bi * bi), a.inv_i, *p * a.cov_keep));
           p += ts;
         }
       } else {
@@ -1138,8 +1146,8 @@ __device__ __forceinline__ void measure_chain(const MeasureArgs<R> &a, long long
 #pragma unroll
         for (int j = 0; j <= i; ++j) {
           const int k = tri(i, j);
-          R v = m[k] * a.cov_keep + delta[i] * delta[j] * a.inv_i;
-          if (i == j) v += eps;
+          R v = fma_(delta[i] * delta[j], a.inv_i, m[k] * a.cov_keep);
+          if (i == j) v = fma_(w2_real, a.inv_i, v);
           packed_store<NT>(fcov, k, toff, v);
           m[k] = v;
         }
@@ -1150,15 +1158,15 @@ __device__ __forceinline__ void measure_chain(const MeasureArgs<R> &a, long long
         for (int j = 0; j < i; ++j) {
           const R aj = delta[NR + j], bj = delta[NR + NC + j];
           const int kr = cre(PR, i, j), ki = cim(PR, i, j);
-          const R vr = m[kr] * a.cov_keep + (ai * aj + bi * bj) * a.inv_i;
-          const R vi = m[ki] * a.cov_keep + (bi * aj - ai * bj) * a.inv_i;
+          const R vr = fma_(fma_(ai, aj, bi * bj), a.inv_i, m[kr] * a.cov_keep);
+          const R vi = fma_(fma_(bi, aj, -(ai * bj)), a.inv_i, m[ki] * a.cov_keep);
           packed_store<NT>(fcov, kr, toff, vr);
           packed_store<NT>(fcov, ki, toff, vi);
           m[kr] = vr;
           m[ki] = -vi;   // the proposals use conj(K) (quirk Q3, :292-298)
         }
         const int kd = cdiag(PR, i);
-        const R vd = m[kd] * a.cov_keep + (ai * ai + bi * bi) * a.inv_i + eps_c;
+        const R vd = fma_(w2_cplx, a.inv_i, fma_(fma_(ai, ai, bi * bi), a.inv_i, m[kd] * a.cov_keep));
         packed_store<NT>(fcov, kd, toff, vd);
         m[kd] = vd;
       }

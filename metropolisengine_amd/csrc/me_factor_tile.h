@@ -94,8 +94,7 @@ struct FactorTile {
 
 // dg = sqrt(d), inv = 1 / sqrt(d) for a normal positive d: hardware estimate, one coupled Newton step for both (g -> sqrt,
 // h -> 1/(2 sqrt)), a residual correction each
-__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// (fma_: me_device.h)
 template <typename R>
 __device__ __forceinline__ void sqrt_and_inverse(R d, R &dg, R &inv) {
   R rs;

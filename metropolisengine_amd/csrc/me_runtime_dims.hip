@@ -45,9 +45,8 @@ struct RuntimeStep {
   const R *weights;      // ME_ENERGY_DIAG_QUAD: D weights (real, then the complex weights twice), device memory
 };
 
-// one explicit fma in both passes: the state written by pass 2 is bit for bit the x' whose energy pass 1 summed
-__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// (fma_, me_device.h: one explicit fma in both passes -- the state written by pass 2 is bit for bit the x' whose energy
+// pass 1 summed)
 
 // Safe by construction: `weights` is non-null for ME_ENERGY_DIAG_QUAD only (fill() below), every other kind gets `iso`
 // (0 for the dense form, whose energy never comes through here).  Round 2's last GPU call core-dumped in an experiment

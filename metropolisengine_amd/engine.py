@@ -537,9 +537,33 @@ class MetropolisEngine:
         return state
 
     def load_state_dict(self, state):
+        """Restore a :meth:`state_dict`.  Everything is validated against THIS engine before the first device write -- a
+        checkpoint of an engine with other fields (e.g. ``reference_energy_ledgers=True``, a tracked covariance, a shared
+        factor) or other shapes raises and leaves the engine untouched."""
+        todo = []
         for name, field in self._STATE_FIELDS:
             if name in state and (name != "factor" or state.get("uses_per_chain_factors", False)):
-                self._set(field, state[name])
+                comps = ctypes.c_int32()
+                self._check(self._lib.me_field_components(self._handle, field, ctypes.byref(comps)))   # NotImplementedError
+                values = np.asarray(state[name], dtype=np.float64)
+                if values.shape != (self.n_chains, comps.value):
+                    raise ValueError("checkpoint field %r has shape %s, this engine keeps %s"
+                                     % (name, values.shape, (self.n_chains, comps.value)))
+                todo.append((field, values))
+        if "step_index" not in state or "measure_step_counter" not in state:
+            raise ValueError("checkpoint lacks the step / measure counters")
+        if int(state["measure_step_counter"]) < 1:
+            raise ValueError("measure_step_counter starts at 1")
+        if "shared_factor" in state:
+            nr, nc = self.num_real_params, self.num_complex_params
+            if self.cov_mode != "pooled":
+                raise ValueError("the checkpoint carries a shared proposal factor: this engine needs cov_mode='pooled'")
+            if np.asarray(state["shared_factor"]).shape != (nr * (nr + 1) // 2 + nc * nc,):
+                raise ValueError("checkpoint shared_factor has the wrong length")
+        if "accepted" in state and "proposed" in state and int(state["accepted"]) > int(state["proposed"]):
+            raise ValueError("checkpoint accept counters are inconsistent")
+        for field, values in todo:
+            self._set(field, values)
         self._check(self._lib.me_set_counters(self._handle, int(state["step_index"]),
                                               int(state["measure_step_counter"])))
         if "shared_factor" in state:

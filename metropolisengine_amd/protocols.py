@@ -20,12 +20,14 @@ import time
 from . import distributed
 
 
-def cycle_protocol(engine, cycles, steps_per_measure=10, pooled="none", backend=None, group=None, fused=False, on_stats=None):
+def cycle_protocol(engine, cycles, steps_per_measure=10, pooled="none", backend=None, group=None, fused=False, on_stats=None,
+                   one_launch=False):
     """Run ``cycles`` x (``steps_per_measure`` x ``step_all`` + ``measure`` [+ pooled statistics]) and return the wall
     seconds of the loop (the engine is synchronised before and after).
 
     ``pooled``: ``"none"``, ``"sync"`` (collect inside the cycle) or ``"overlap"`` (collect one cycle later).
     ``fused``: one ``step_all(steps_per_measure)`` launch instead of ``steps_per_measure`` launches.
+    ``one_launch``: the sweeps AND the measure of a cycle as one launch (``engine.cycle``, ``me_cycle``).
     ``on_stats(cycle, stats)`` receives every cycle's pooled statistics (in the overlapped form: of the cycle before).
     """
     if pooled not in ("none", "sync", "overlap"):
@@ -35,12 +37,15 @@ def cycle_protocol(engine, cycles, steps_per_measure=10, pooled="none", backend=
     last = None
     t0 = time.perf_counter()
     for cycle in range(cycles):
-        if fused:
-            engine.step_all(steps_per_measure)
+        if one_launch:
+            engine.cycle(steps_per_measure)
         else:
-            for _ in range(steps_per_measure):
-                engine.step_all()
-        engine.measure()
+            if fused:
+                engine.step_all(steps_per_measure)
+            else:
+                for _ in range(steps_per_measure):
+                    engine.step_all()
+            engine.measure()
         if pooled == "sync":
             last = distributed.pooled_statistics(engine, group, backend=backend)
             if on_stats:
@@ -76,6 +81,10 @@ def config5(engine, n_local, world, cycles=200, steps_per_measure=10, warm_cycle
         seconds[form] = reduce_max(dt)
         stats = last or stats
     total = float(n_local) * world * steps_per_measure * cycles
+    if hasattr(engine, "cycle"):
+        # the same protocol with each cycle's sweeps + measure as ONE launch (me_cycle), reduction overlapped
+        dt, _ = cycle_protocol(engine, cycles, steps_per_measure, "overlap", backend=backend, group=group, one_launch=True)
+        out["chain_steps_per_s_one_launch_cycles_overlapped"] = total / reduce_max(dt)
     out["chain_steps_per_s"] = total / seconds["sync"]
     out["chain_steps_per_s_overlapped"] = total / seconds["overlap"]
     out["chain_steps_per_s_without_allreduce"] = total / seconds["none"]

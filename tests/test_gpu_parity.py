@@ -271,6 +271,45 @@ def test_checkpoint_round_trip_pooled_shape_and_counters():
     assert np.array_equal(a.shared_factor(), b.shared_factor())
 
 
+def test_checkpoint_round_trip_reference_energy_ledgers_and_validation():
+    """Quirk-Q5 mode keeps a separate energy_total row: it travels with the checkpoint, and a checkpoint that does not fit
+    the engine it is loaded into (other flags, other mode, other shapes) raises BEFORE anything is written."""
+    args = (me.DiagQuadratic((1, 2), (1, 2)), None, [0.1, 0.2], [0.1j, 0.2])
+    kw = dict(temp=1.0, n_chains=300, seed=12, dtype="f64")
+    a = me.MetropolisEngine(*args, reference_energy_ledgers=True, **kw)
+    for _ in range(6):
+        a.step_all(2)
+        a.step_real_group()
+        a.step_complex_group()
+        a.measure()
+    state = a.state_dict()
+    assert "energy_total" in state
+    b = me.MetropolisEngine(*args, reference_energy_ledgers=True, **kw)
+    b.load_state_dict(state)
+    for e in (a, b):
+        e.step_all(3)
+        e.step_real_group(2)
+        e.measure()
+    for field in (0, 1, 2, 3, 4, 5, 7):
+        assert np.array_equal(a._get(field), b._get(field)), field
+    assert a.accept_stats() == b.accept_stats()
+    # ... into an engine WITHOUT the two-ledger flag: refused, and the target keeps its state, counters and statistics
+    plain = me.MetropolisEngine(*args, **kw)
+    plain.step_all(4)
+    before = [plain._get(f) for f in range(6)], plain.accept_stats(), plain.measure_step_counter, plain.step_counter
+    with pytest.raises(NotImplementedError):
+        plain.load_state_dict(state)
+    wrong_shape = dict(plain.state_dict())
+    wrong_shape["mean"] = wrong_shape["mean"][:100]
+    with pytest.raises(ValueError, match="shape"):
+        plain.load_state_dict(wrong_shape)
+    pooled_state = dict(plain.state_dict(), shared_factor=np.ones(2 * 3 // 2 + 4))
+    with pytest.raises(ValueError, match="pooled"):
+        plain.load_state_dict(pooled_state)
+    after = [plain._get(f) for f in range(6)], plain.accept_stats(), plain.measure_step_counter, plain.step_counter
+    assert all(np.array_equal(x, y) for x, y in zip(before[0], after[0])) and before[1:] == after[1:]
+
+
 def test_set_rejects_partial_mixed_widths_before_writing():
     """me_set validates before any device write: a partial width update of a mixed engine leaves the widths untouched."""
     eng = me.MetropolisEngine(me.DiagQuadratic((1, 2), (1, 2)), None, [0.0] * 2, [0j] * 2, temp=1.0, n_chains=64, seed=3)

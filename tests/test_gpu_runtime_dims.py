@@ -132,7 +132,7 @@ def test_dense_energy_and_shared_factor_at_120_real(shape):
     assert np.all(np.abs(eng._get(0)[:, 0]) < 1.0)
 
 
-@pytest.mark.parametrize("nr,nc,dtype", [(96, 0, "f64"), (120, 0, "f64"), (120, 0, "f32"), (60, 25, "f64"), (200, 0, "f64")])
+@pytest.mark.parametrize("nr,nc,dtype", [(96, 0, "f64"), (120, 0, "f64"), (120, 0, "f32"), (60, 25, "f64"), (140, 0, "f64"), (250, 0, "f32")])
 def test_pooled_moments_and_adapt_pooled_shape_beyond_75_degrees_of_freedom(nr, nc, dtype):
     """me_pooled_moments used to stop at 3 072 moment entries (about 75 real degrees of freedom): stage 1 of the reduction
     now runs in passes of 3 072 entries (tiles of 64 / 32 / 16 chains by LDS size), so every engine that accepts

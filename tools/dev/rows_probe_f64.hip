@@ -13,7 +13,7 @@ __global__ void __launch_bounds__(64) k(double *rw, long long n) {
   for (int r = 0; r < RW; ++r) rw[r * n + c] = x[r] * 1.0000001 + 1e-30;
 }
 int main() {
-  for (int lg : {20, 22}) {
+  for (int lg : {17, 18, 19, 20, 21, 22}) {   // the ramp: time against chain count (fixed cost + slope)
     const long long n = 1ll << lg;
     double *rw; (void)hipMalloc(&rw, 8 * n * 18); (void)hipMemset(rw, 0, 8 * n * 18);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);

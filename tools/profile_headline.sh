@@ -4,7 +4,7 @@
 #   passes (one counter per run, --kernel-trace only, as MI355X_MICROARCH.md prescribes).  Output: gpurun_out/r02_prof/
 set -e
 export TMPDIR=/tmp
-OUT=gpurun_out/r02_prof
+OUT=${OUT:-gpurun_out/r03_prof}
 mkdir -p $OUT
 COMMON="--gpus 1 --cpu-seconds 0 --fused-sweeps 0 --extras 0 --hbm-chains-log2 0"
 for dt in f64 f32; do
