@@ -267,6 +267,11 @@ struct StateField : Field<R> {
 
 // packed sizes up to this are kept in registers by the per-chain factor kernels (build.py: MAX_PACKED_IN_REGISTERS)
 constexpr int kMaxPackedInRegisters = 160;
+// float64, pure real spaces: k_step streams per-chain factors with more entries than this instead of holding them
+#ifndef ME_STREAM_F64_ENTRIES
+#define ME_STREAM_F64_ENTRIES 100000      // experiment knob; 96 = stream the 136-entry factor of 16 real parameters
+#endif
+constexpr int kStreamF64Entries = ME_STREAM_F64_ENTRIES;
 
 // ------------------------------------------------------------------------------------------------ energies
 // An energy is a small by-value functor evaluated on the chain's register-resident state
@@ -753,8 +758,13 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   const bool stale_total = MIXED && GROUP == GROUP_ALL && a.stale_total != 0;
   constexpr bool PER_CHAIN = CK == CK_PER_CHAIN || CK == CK_PER_CHAIN_NT;
   constexpr int PF = PER_CHAIN ? NR * (NR + 1) / 2 + NC * NC : 0;
-  // per-chain factors beyond the register-resident size are streamed (pure real spaces only)
-  constexpr bool STREAM_FACTOR = PER_CHAIN && PF > kMaxPackedInRegisters;
+  // per-chain factors beyond the register-resident size are streamed (pure real spaces only) -- and so are float64 factors
+  // of more than kStreamF64Entries entries: 136 doubles (16 real parameters) are 272 registers, ONE wavefront per SIMD,
+  // and with nobody to run beside it a wavefront's arithmetic (RNG, L g) adds to its load time -- 246 us against a
+  // memory-only floor of 214 us at 2^20 chains (tools/dev/cov_probe_f64.hip).  Streamed in two 128-byte chunks per lane
+  // the kernel needs ~100 registers and four wavefronts share a SIMD.
+  constexpr bool STREAM_FACTOR = PER_CHAIN && (PF > kMaxPackedInRegisters ||
+                                               (!INJECT && sizeof(R) == 8 && NC == 0 && PF > kStreamF64Entries));
   static_assert(!STREAM_FACTOR || NC == 0, "streamed per-chain factors exist for pure real parameter spaces");
   const TiledField<R> ffac(a.factor, a.n, STREAM_FACTOR ? 0 : PF);
   for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < a.n; c += stride) {
