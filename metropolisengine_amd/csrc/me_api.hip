@@ -161,6 +161,7 @@ struct me_engine {
   unsigned long long *accept_slots = nullptr, *accept_total = nullptr;
   long long n_slots = 0;
   unsigned long long proposed = 0;
+  bool x_tiled = false;         // the state field is tile-major (KernelSet::tiled_state)
   int width_rows = 1;           // 3 for mixed engines: [sampling_width, real group, complex group]
   bool widths_synced = true;    // mixed engines: rows 1, 2 are implied equal to row 0 (state after a step_all)
   unsigned int *status = nullptr;
@@ -543,7 +544,8 @@ int me_create(const me_config *c, me_engine **out) {
   ME_CREATE_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   e->own_stream = true;
   const size_t n = (size_t)e->n, es = e->esize;
-  ME_CREATE_HIP(hipMalloc(&e->x, n * e->d * es));
+  e->x_tiled = ks->tiled_state;
+  ME_CREATE_HIP(hipMalloc(&e->x, (e->x_tiled ? (n + 63) / 64 * 64 : n) * e->d * es));   // tile-major: whole 64-chain tiles
   e->stale_total = (c->flags & ME_FLAG_REFERENCE_ENERGY_LEDGERS) != 0;
   ME_CREATE_HIP(hipMalloc(&e->energy, n * (e->n_terms + (e->stale_total ? 1 : 0)) * es));
   e->width_rows = (e->nr > 0 && e->nc > 0) ? 3 : 1;
@@ -656,7 +658,7 @@ int me_create(const me_config *c, me_engine **out) {
   }
   int rc = ME_OK;
   std::vector<double> width_row((size_t)e->width_rows, c->sampling_width);
-  if ((rc = broadcast(e, e->x, init)) || (rc = broadcast(e, e->mean, init)) || (rc = broadcast(e, e->obs_mean, obs)) ||
+  if ((rc = broadcast(e, e->x, init, e->x_tiled)) || (rc = broadcast(e, e->mean, init)) || (rc = broadcast(e, e->obs_mean, obs)) ||
       (rc = broadcast(e, e->width, width_row)) || (e->cov && (rc = broadcast(e, e->cov, c0, true))) ||
       (e->factor && (rc = broadcast(e, e->factor, f0, true)))) {
     g_create_error = e->err;
@@ -881,7 +883,7 @@ int commit_measure(me_engine *e, const MeasureLaunch &l) {
     // widths: a synced mixed engine keeps only row 0 current; mirror it so that the series reads like the reference's
     const int rows_valid = (e->width_rows == 3 && e->widths_synced) ? 1 : e->width_rows;
     ME_HIP(e, launch_trace(e->x, e->energy, e->width, e->n, e->d, e->n_terms, rows_valid, e->dtype, e->trace_chains, e->trace_stride,
-                           e->trace_dev + e->trace_rows * cols * e->trace_chains, e->stream));
+                           e->trace_dev + e->trace_rows * cols * e->trace_chains, e->stream, e->x_tiled));
     if (rows_valid != e->width_rows) {
       double *row = e->trace_dev + e->trace_rows * cols * e->trace_chains + (size_t)(e->d + e->n_terms) * e->trace_chains;
       for (int r = 1; r < 3; ++r)
@@ -992,7 +994,8 @@ int me_get(me_engine *e, int32_t field, int64_t chain_begin, int64_t n_chains, d
   int rc = field_info(e, field, &ptr, &comps);
   if (rc != ME_OK) return rc;
   if (n_chains == 0) return ME_OK;
-  if (field == ME_FIELD_COV || field == ME_FIELD_FACTOR) return copy_tiled(e, ptr, comps, chain_begin, n_chains, dst, nullptr);
+  if (field == ME_FIELD_COV || field == ME_FIELD_FACTOR || (field == ME_FIELD_PARAMS && e->x_tiled))
+    return copy_tiled(e, ptr, comps, chain_begin, n_chains, dst, nullptr);
   std::vector<unsigned char> tmp((size_t)comps * n_chains * e->esize);
   for (int r = 0; r < comps; ++r)
     ME_HIP(e, hipMemcpyAsync(tmp.data() + (size_t)r * n_chains * e->esize,
@@ -1025,7 +1028,7 @@ int me_set(me_engine *e, int32_t field, int64_t chain_begin, int64_t n_chains, c
   if (field == ME_FIELD_WIDTH && e->width_rows == 3 && (chain_begin != 0 || n_chains != e->n))
     return fail(e, ME_ERR_INVALID, "widths of a mixed engine must be set for all chains at once");
   if (n_chains == 0) return ME_OK;
-  if (field == ME_FIELD_COV || field == ME_FIELD_FACTOR) {
+  if (field == ME_FIELD_COV || field == ME_FIELD_FACTOR || (field == ME_FIELD_PARAMS && e->x_tiled)) {
     rc = copy_tiled(e, ptr, comps, chain_begin, n_chains, nullptr, src);
     if (rc != ME_OK) return rc;
     if (field == ME_FIELD_FACTOR) e->cov_kind = CK_PER_CHAIN;
@@ -1114,7 +1117,7 @@ int enqueue_pooled_moments(me_engine *e, void *device_out, int64_t n_doubles) {
   ME_HIP(e, hipSetDevice(e->device));
   hipError_t err = launch_pool_reduce(e->x, e->n, e->nr, e->nc, e->dtype, e->accept_slots, e->n_slots,
                                       (double)e->proposed, e->pool_partials, (double *)device_out, e->stream,
-                                      e->ks->pool_stage1);
+                                      e->ks->pool_stage1, e->x_tiled);
   if (err == hipErrorInvalidValue) return fail(e, ME_ERR_UNSUPPORTED, "pooled moments: dimension too large for the reduction kernel");
   ME_HIP(e, err);
   return ME_OK;

@@ -175,13 +175,14 @@ __global__ void __launch_bounds__(THREADS, 2) k_step_dense64_bf16x3(StepArgs<flo
   unsigned int wave_accepted = 0;
   bool bad_energy = false, bad_width = false;
   const long long stride = (long long)gridDim.x * THREADS;
-  const Field<float> fx(a.x, a.n, D), fe(a.energy, a.n, 1), fw(a.width, a.n, 1);
+  const XField<float, D> fx(a.x, a.n);      // tile-major: a wavefront's 64 rows are one contiguous 16 KiB block
+  const Field<float> fe(a.energy, a.n, 1), fw(a.width, a.n, 1);
 
   // every lane stays active (MFMA and permlane need the whole wavefront): tail lanes shadow the last chain
   long long base = (long long)blockIdx.x * THREADS + (threadIdx.x & ~63);
   bool have = base < a.n;
   bool live = false;
-  unsigned int coff = 0;
+  unsigned int coff = 0, xoff = 0;
   unsigned long long gid = 0;
   float x[D], e = 0.0f, w = 0.0f;
   // Loads are issued in the order the first sweep consumes them (width, then rows 0, 1, 2, ...): memory returns in
@@ -192,13 +193,14 @@ __global__ void __launch_bounds__(THREADS, 2) k_step_dense64_bf16x3(StepArgs<flo
     live = c_raw < a.n;
     const long long c = live ? c_raw : a.n - 1;
     coff = (unsigned int)c * 4u;
+    xoff = fx.offset(c);
     gid = a.chain_offset + (unsigned long long)c;
     w = fw.load(0, coff);
     e = fe.load(0, coff);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      x[d] = fx.load(d, coff);
+      x[d] = fx.load(d, xoff);
       if ((d & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -276,7 +278,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_step_dense64_bf16x3(StepArgs<flo
     bad_width |= live && !(w > 0.0f);
     if (live) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) fx.store(d, coff, x[d]);
+      for (int d = 0; d < D; ++d) fx.store(d, xoff, x[d]);
       fe.store(0, coff, e);
       fw.store(0, coff, w);
     }

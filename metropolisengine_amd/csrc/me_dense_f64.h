@@ -54,6 +54,9 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 #ifndef ME_DENSE64_F64_RNG_UNROLL
 #define ME_DENSE64_F64_RNG_UNROLL 2     // 2 blocks (4 Box-Muller pairs) per iteration: -2.5 % on the fused sweep against 1; 4: no further gain
 #endif
+#ifndef ME_DENSE64_F64_PRIO
+#define ME_DENSE64_F64_PRIO 0
+#endif
 #ifndef ME_DENSE64_F64_NT
 #define ME_DENSE64_F64_NT 0             // experiment: bit 0 = state loads non-temporal, bit 1 = state stores non-temporal
 #endif
@@ -162,7 +165,9 @@ __global__ void __launch_bounds__(kDense64F64Threads, 2)
   const int cl = lane & 31, half = lane >> 5;             // chain of the tile, and which 32 rows of it this lane owns
   unsigned int wave_accepted = 0;
   bool bad_energy = false, bad_width = false;
-  const Field<double> fx(a.x, a.n, D), fe(a.energy, a.n, 1), fw(a.width, a.n, 1);
+  // the state is tile-major (me_device.h: XField): a wavefront's 32 chains x 64 rows are half of one contiguous 32 KiB block
+  const TiledField<double> fx(a.x, a.n, D);
+  const Field<double> fe(a.energy, a.n, 1), fw(a.width, a.n, 1);
   const long long n_tiles = (a.n + kTileChains64 - 1) / kTileChains64;
   const long long tile_stride = (long long)gridDim.x * (kDense64F64Threads / 64);
 
@@ -171,19 +176,25 @@ __global__ void __launch_bounds__(kDense64F64Threads, 2)
     const long long c_raw = tile * kTileChains64 + cl;
     return c_raw < a.n ? c_raw : a.n - 1;
   };
-  // lane offset into the state field: the chain, plus 32 rows for the upper half (a row offset cannot be per lane)
-  auto state_off = [&](const Field<double> &f, long long c) { return (unsigned int)c * 8u + (unsigned int)half * (unsigned int)H * f.row_bytes; };
+  // lane offset into the state field: the chain's place in its tile, plus 32 rows for the upper half (the row index of
+  // load / store is a wave-uniform immediate)
+  auto state_off = [&](long long c) { return tiled_offset<double>(c, D) + (unsigned int)half * (unsigned int)H * TiledField<double>::kEntryBytes; };
   long long tile = (long long)blockIdx.x * (kDense64F64Threads / 64) + wave;
   double x[H], e = 0.0, w = 0.0;
   if (tile < n_tiles) {
     const long long c = chain_of(tile);
-    const unsigned int xoff = state_off(fx, c);
+    const unsigned int xoff = state_off(c);
 #pragma unroll
     for (int i = 0; i < H; ++i) x[i] = (ME_DENSE64_F64_NT & 1) ? fx.load_nt(i, xoff) : fx.load(i, xoff);
     e = fe.load(0, (unsigned int)c * 8u);
     w = fw.load(0, (unsigned int)c * 8u);
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);        // enter the loop with nothing pending (see the end of the tile loop)
+#if ME_DENSE64_F64_PRIO
+  // the two wavefronts of a SIMD (wave, wave + 4) get different issue priorities: one runs ahead of the other instead of
+  // both finishing their tiles at the same moment
+  if (wave < 4) __builtin_amdgcn_s_setprio(2);
+#endif
   if constexpr (ME_DENSE64_F64_STAGGER > 0) {
     // the two wavefronts of a SIMD run the same program and start together: delay the second half of the workgroup so
     // that one wavefront's memory phases fall into the other's arithmetic (guide: two waves per SIMD, item 9)
@@ -201,15 +212,12 @@ __global__ void __launch_bounds__(kDense64F64Threads, 2)
     const long long next = tile + tile_stride;
     const bool have_next = next < n_tiles;
     double xn[H], en = 0.0, wn = 0.0;
-    // The row offsets (row x n x 8 bytes, scalar operands of the buffer loads / stores) are loop-invariant: left alone,
-    // hipcc keeps all of them live across the whole tile loop and spills.  An opaque copy per tile makes them cheap
-    // scalar arithmetic next to each access instead.
-    Field<double> fxt = fx;
-    asm volatile("" : "+s"(fxt.row_bytes));
+    // (tile-major rows are compile-time immediates of the buffer instructions: nothing loop-invariant to keep in registers)
+    const TiledField<double> &fxt = fx;
     auto prefetch = [&]() {
       if (have_next) {       // wave-uniform
         const long long cn = chain_of(next);
-        const unsigned int noff = state_off(fxt, cn);
+        const unsigned int noff = state_off(cn);
 #pragma unroll
         for (int i = 0; i < H; ++i) xn[i] = (ME_DENSE64_F64_NT & 1) ? fxt.load_nt(i, noff) : fxt.load(i, noff);
         en = fe.load(0, (unsigned int)cn * 8u);
@@ -311,7 +319,7 @@ __global__ void __launch_bounds__(kDense64F64Threads, 2)
     // everything".  Wait for them here instead -- they were issued most of a tile of arithmetic ago.
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
     if (live) {
-      const unsigned int xoff = state_off(fxt, c);
+      const unsigned int xoff = state_off(c);
 #pragma unroll
       for (int i = 0; i < H; ++i) {
         if constexpr ((ME_DENSE64_F64_NT & 2) != 0) fxt.store_nt(i, xoff, x[i]);

@@ -152,16 +152,17 @@ __global__ void __launch_bounds__(kDenseBlockThreads, 2) k_step_dense64_mfma(Ste
   unsigned int wave_accepted = 0;
   bool bad_energy = false, bad_width = false;
   const long long stride = (long long)gridDim.x * kDenseBlockThreads;
-  const Field<float> fx(a.x, a.n, D), fe(a.energy, a.n, 1), fw(a.width, a.n, 1);
+  const XField<float, D> fx(a.x, a.n);
+  const Field<float> fe(a.energy, a.n, 1), fw(a.width, a.n, 1);
   // every lane stays active (MFMA and permlane need the whole wavefront): tail lanes shadow the last chain
   for (long long base = (long long)blockIdx.x * kDenseBlockThreads + (threadIdx.x & ~63); base < a.n; base += stride) {
     const long long c_raw = base + lane;
     const bool live = c_raw < a.n;
     const long long c = live ? c_raw : a.n - 1;
-    const unsigned int coff = (unsigned int)c * 4u;
+    const unsigned int coff = (unsigned int)c * 4u, xoff = fx.offset(c);
     float x[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) x[d] = fx.load(d, coff);
+    for (int d = 0; d < D; ++d) x[d] = fx.load(d, xoff);
     float e = fe.load(0, coff);
     float w = fw.load(0, coff);
     const unsigned long long gid = a.chain_offset + (unsigned long long)c;
@@ -236,7 +237,7 @@ __global__ void __launch_bounds__(kDenseBlockThreads, 2) k_step_dense64_mfma(Ste
     bad_width |= live && !(w > 0.0f);
     if (live) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) fx.store(d, coff, x[d]);
+      for (int d = 0; d < D; ++d) fx.store(d, xoff, x[d]);
       fe.store(0, coff, e);
       fw.store(0, coff, w);
     }

@@ -265,11 +265,45 @@ struct StateField : Field<R> {
   }
 };
 
+// The chain state x[D] as the per-chain kernels address it.  Parameter spaces with fewer than kTiledStateDof real degrees of
+// freedom keep it component-major (x[row * n + chain]: 18-34 rows, where the layout costs nothing);
+// larger ones keep it TILE-major like the packed fields ([tile of 64 chains][D rows][64 lanes]).  Measured for 64
+// parameters in float64 at 2^19 chains (tools/dev/state_layout_probe64.hip, the geometry of k_step_dense64_f64, no
+// arithmetic): 64 rows 4 MiB apart 101-116 us, one contiguous 32 KiB block per tile 82-88 us -- a quarter of the memory
+// phase of BASELINE config 4.  The layout is a compile-time property of the kernel set (KernelSet::tiled_state); the host
+// gathers / scatters tiles in me_get / me_set; the runtime-dimension set stays component-major.
+constexpr int kTiledStateDof = 32;
+template <typename R, int D, bool NTS = false>
+struct XField {
+  static constexpr bool kTiled = D >= kTiledStateDof;
+  std::conditional_t<kTiled, TiledField<R>, StateField<R, NTS>> f;
+  __device__ __forceinline__ XField(const R *base, long long n) : f(base, n, D) {}
+  // per-lane offset of chain c (the row index is the other argument of load / store)
+  static __device__ __forceinline__ unsigned int offset(long long c) {
+    if constexpr (kTiled) return tiled_offset<R>(c, D);
+    else return (unsigned int)c * (unsigned int)sizeof(R);
+  }
+  __device__ __forceinline__ R load(int row, unsigned int off) const {
+    if constexpr (kTiled && NTS) return f.load_nt(row, off);
+    else return f.load(row, off);
+  }
+  __device__ __forceinline__ void store(int row, unsigned int off, R value) const {
+    if constexpr (kTiled && NTS) f.store_nt(row, off, value);
+    else f.store(row, off, value);
+  }
+};
+// the same address computation for kernels that walk the state with plain pointers
+template <typename R, int D>
+__device__ __forceinline__ long long state_index(long long c, int row, long long n) {
+  if constexpr (D >= kTiledStateDof) return ((c >> 6) * (long long)D + row) * 64 + (c & 63);
+  else return (long long)row * n + c;
+}
+
 // packed sizes up to this are kept in registers by the per-chain factor kernels (build.py: MAX_PACKED_IN_REGISTERS)
 constexpr int kMaxPackedInRegisters = 160;
 // float64, pure real spaces: k_step streams per-chain factors with more entries than this instead of holding them
 #ifndef ME_STREAM_F64_ENTRIES
-#define ME_STREAM_F64_ENTRIES 100000      // experiment knob; 96 = stream the 136-entry factor of 16 real parameters
+#define ME_STREAM_F64_ENTRIES 96          // the 136-entry factor of 16 real parameters streams; a huge value: never
 #endif
 constexpr int kStreamF64Entries = ME_STREAM_F64_ENTRIES;
 
@@ -737,6 +771,24 @@ __device__ __forceinline__ void run_sweeps(const StepArgs<R> &a, const Energy &e
 // Widths of mixed engines are three rows [sampling_width, real group, complex group] (:93-99, :429-456):
 // step_all adapts row 0 and mirrors it into the group widths (:436-437), a group step adapts only its own row.
 
+// Wavefronts that share a SIMD start together, load together and then compete for the vector pipe together: all of them
+// finish their first sweep at the same late moment, and until then nothing is stored (the ramp: a fixed ~4.6 us on top of
+// the memory-only kernel's at 2^20 chains, profiles/r03_probes_and_variants.txt).  Different issue priorities for the
+// workgroups of a launch let one wavefront of each SIMD run ahead instead.  ME_STEP_PRIO_SHIFT < 0: off.
+#ifndef ME_STEP_PRIO_SHIFT
+#define ME_STEP_PRIO_SHIFT 8     // measured 0 .. 12 on the float64 headline kernel: 4 .. 10 all give 51.5 -> 49.0 us, 0 / 2 / 12 half of that
+#endif
+__device__ __forceinline__ void stagger_priority() {
+#if ME_STEP_PRIO_SHIFT >= 0
+  switch ((blockIdx.x >> ME_STEP_PRIO_SHIFT) & 3u) {
+    case 0: __builtin_amdgcn_s_setprio(3); break;
+    case 1: __builtin_amdgcn_s_setprio(2); break;
+    case 2: __builtin_amdgcn_s_setprio(1); break;
+    default: break;
+  }
+#endif
+}
+
 template <typename R, int NR, int NC, class Energy, int CK, bool INJECT = false, int GROUP = GROUP_ALL, bool NTS = false>
 __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   constexpr int D = NR + 2 * NC;
@@ -744,13 +796,15 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   static_assert(GROUP == GROUP_ALL || MIXED, "group-wise kernels exist for mixed engines only");
   using N_ = Num<R>;
 
+  stagger_priority();
   if constexpr (!INJECT) N_::prepare();
   energy_prepare(en, 0);
   unsigned int wave_accepted = 0;
   bool bad_energy = false, bad_width = false;
   const long long stride = (long long)gridDim.x * blockDim.x;   // 64 threads per block, or 256 for fused sweeps
   using Ledger = EnergyLedger<R, Energy, GROUP>;
-  const StateField<R, NTS> fx(a.x, a.n, D), fe(a.energy, a.n, Ledger::T + (MIXED ? 1 : 0)), fw(a.width, a.n, MIXED ? 3 : 1);
+  const XField<R, D, NTS> fx(a.x, a.n);
+  const StateField<R, NTS> fe(a.energy, a.n, Ledger::T + (MIXED ? 1 : 0)), fw(a.width, a.n, MIXED ? 3 : 1);
   // The reference keeps TWO ledgers: step_all of a mixed engine decides against `energy_total` and
   // updates only that (metropolis_engine.py:252-255); group steps use `energy[term]` (:214-221, :230-237).  With
   // ME_FLAG_REFERENCE_ENERGY_LEDGERS the total lives in ledger row T and this kernel touches only the rows the
@@ -769,9 +823,10 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   const TiledField<R> ffac(a.factor, a.n, STREAM_FACTOR ? 0 : PF);
   for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
+    const unsigned int xoff = fx.offset(c);
     R x[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) x[d] = fx.load(d, coff);
+    for (int d = 0; d < D; ++d) x[d] = fx.load(d, xoff);
     Ledger ledger;
     R total_q5 = R(0);
     if (stale_total) total_q5 = fe.load(Ledger::T, coff);
@@ -902,7 +957,7 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
     }
     bad_width |= !(w > R(0));
 #pragma unroll
-    for (int d = 0; d < D; ++d) fx.store(d, coff, x[d]);
+    for (int d = 0; d < D; ++d) fx.store(d, xoff, x[d]);
     if (stale_total) fe.store(Ledger::T, coff, total_q5);
     else ledger.store(fe, coff);
     fw.store(MIXED ? GROUP : 0, coff, w);   // after a mixed step_all rows 1, 2 are implied equal to row 0 (host flag)
@@ -927,7 +982,7 @@ __global__ void __launch_bounds__(kStepThreads) k_init_energy(const R *xs, R *en
   for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < n; c += stride) {
     R x[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) x[d] = xs[(long long)d * n + c];
+    for (int d = 0; d < D; ++d) x[d] = xs[state_index<R, D>(c, d, n)];
     constexpr int T = term_count<Energy>::value;   // every term of the ledger (initialize_energy_dict, :152-155)
     bool finite = true;
     R total = R(0);
@@ -1199,7 +1254,8 @@ __global__ void __launch_bounds__(kStepThreads, ME_MEASURE_WAVES) k_measure(Meas
   constexpr int NOBS = 2 * NR + NC;
   bool bad_pivot = false;
   const long long stride = (long long)gridDim.x * kStepThreads;
-  const Field<R> fx(a.x, a.n, D), fw(a.width, a.n, (NR > 0 && NC > 0) ? 3 : 1), fmean(a.mean, a.n, D), fobs(a.obs_mean, a.n, NOBS);
+  const XField<R, D> fx(a.x, a.n);
+  const Field<R> fw(a.width, a.n, (NR > 0 && NC > 0) ? 3 : 1), fmean(a.mean, a.n, D), fobs(a.obs_mean, a.n, NOBS);
   // Large matrices (P > kMaxPackedInRegisters) are statistics only (no factors, FUSED = false) and take the streaming
   // path below; their field may pass the 4 GiB one descriptor spans and is walked with a 64-bit pointer instead.
   constexpr bool STREAM = PER_CHAIN_COV && P > kMaxPackedInRegisters;
@@ -1208,9 +1264,10 @@ __global__ void __launch_bounds__(kStepThreads, ME_MEASURE_WAVES) k_measure(Meas
   __shared__ R s_delta[STREAM ? D : 1][kStepThreads];
   for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
+    const unsigned int xoff = fx.offset(c);
     R x[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) x[d] = fx.load(d, coff);
+    for (int d = 0; d < D; ++d) x[d] = fx.load(d, xoff);
     measure_chain<R, NR, NC, PER_CHAIN_COV, FUSED, NT, NTM>(a, c, x, fmean, fobs, fcov, ffac, s_delta, [&](R &w_real, R &w_cplx) {
       constexpr bool MIXED = NR > 0 && NC > 0;
       w_real = fw.load((MIXED && a.split_widths) ? 1 : 0, coff);
@@ -1246,15 +1303,17 @@ __global__ void ME_STEP_BOUNDS k_cycle(StepArgs<R> a, MeasureArgs<R> ma, Energy 
   bool bad_energy = false, bad_width = false, bad_pivot = false;
   const long long stride = (long long)gridDim.x * blockDim.x;
   using Ledger = EnergyLedger<R, Energy, GROUP_ALL>;
-  const Field<R> fx(a.x, a.n, D), fe(a.energy, a.n, Ledger::T + (MIXED ? 1 : 0)), fw(a.width, a.n, MIXED ? 3 : 1);
+  const XField<R, D> fx(a.x, a.n);
+  const Field<R> fe(a.energy, a.n, Ledger::T + (MIXED ? 1 : 0)), fw(a.width, a.n, MIXED ? 3 : 1);
   const Field<R> fmean(ma.mean, a.n, D), fobs(ma.obs_mean, a.n, NOBS);
   const TiledField<R> fcov(ma.cov, a.n, P), ffac(ma.factor, a.n, P);
   const bool stale_total = MIXED && a.stale_total != 0;
   for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
+    const unsigned int xoff = fx.offset(c);
     R x[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) x[d] = fx.load(d, coff);
+    for (int d = 0; d < D; ++d) x[d] = fx.load(d, xoff);
     Ledger ledger;
     R total_q5 = R(0);
     if (stale_total) total_q5 = fe.load(Ledger::T, coff);
@@ -1279,7 +1338,7 @@ __global__ void ME_STEP_BOUNDS k_cycle(StepArgs<R> a, MeasureArgs<R> ma, Energy 
     // the state goes out first: a block of stores in front of measure_chain's loads costs nothing, and x dies as soon as the
     // means and observables are formed
 #pragma unroll
-    for (int d = 0; d < D; ++d) fx.store(d, coff, x[d]);
+    for (int d = 0; d < D; ++d) fx.store(d, xoff, x[d]);
     if (stale_total) fe.store(Ledger::T, coff, total_q5);
     else ledger.store(fe, coff);
     fw.store(0, coff, w);

@@ -42,7 +42,7 @@ constexpr int kMaxEntries = 12;   // moment entries per thread and pass -> 3072 
 // No atomics: a thousand blocks adding to the same ~200 words with fp64 atomics serialise at the memory side (measured:
 // the one-launch atomic version was 2x slower).
 template <typename R, int TILE>
-__global__ void __launch_bounds__(kBlockThreads) k_pool_reduce(const R *x, long long n, int nr, int nc, int entry_base, double *partials) {
+__global__ void __launch_bounds__(kBlockThreads) k_pool_reduce(const R *x, long long n, int nr, int nc, int entry_base, int tiled, double *partials) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R *tile = reinterpret_cast<R *>(smem_raw);
   constexpr int kTilePitch = TILE + 1;
@@ -51,6 +51,8 @@ __global__ void __launch_bounds__(kBlockThreads) k_pool_reduce(const R *x, long 
   const int n_pair = d * (d + 1) / 2;
   const int n_entries = 1 + n_aug + n_pair;
   const int tid = threadIdx.x;
+  // where row r of chain c sits: component-major, or the tile-major state of the larger register-resident sets
+  auto at = [&](int r, long long c) -> long long { return tiled ? ((c >> 6) * (long long)d + r) * 64 + (c & 63) : (long long)r * n + c; };
 
   // decode this thread's entries once: entry 0 = count, 1..n_aug = row sums, then the pair products (i >= j)
   int row_i[kMaxEntries], row_j[kMaxEntries];
@@ -80,13 +82,13 @@ __global__ void __launch_bounds__(kBlockThreads) k_pool_reduce(const R *x, long 
       R v = 0;
       if (col < valid) {
         const long long c = base + col;
-        if (r < d) v = x[(long long)r * n + c];
+        if (r < d) v = x[at(r, c)];
         else if (r < d + nr) {
-          const R xv = x[(long long)(r - d) * n + c];
+          const R xv = x[at(r - d, c)];
           v = xv < 0 ? -xv : xv;
         } else {
           const int j = r - d - nr;
-          const R re = x[(long long)(nr + j) * n + c], im = x[(long long)(nr + nc + j) * n + c];
+          const R re = x[at(nr + j, c)], im = x[at(nr + nc + j, c)];
           v = (R)sqrt((double)re * re + (double)im * im);
         }
       }
@@ -247,25 +249,27 @@ __global__ void __launch_bounds__(kSumThreads) k_sum_slots(const unsigned long l
 template <typename R>
 __global__ void __launch_bounds__(kBlockThreads) k_trace(const R *x, const R *energy, const R *width, long long n, int d,
                                                          int n_terms, int width_rows, long long n_traced, long long stride,
-                                                         double *out) {
+                                                         int tiled, double *out) {
   const long long t = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
   if (t >= n_traced) return;
   const long long c = t * stride;
-  for (int k = 0; k < d; ++k) out[(long long)k * n_traced + t] = (double)x[(long long)k * n + c];
+  for (int k = 0; k < d; ++k)
+    out[(long long)k * n_traced + t] = (double)x[tiled ? ((c >> 6) * (long long)d + k) * 64 + (c & 63) : (long long)k * n + c];
   for (int k = 0; k < n_terms; ++k) out[(long long)(d + k) * n_traced + t] = (double)energy[(long long)k * n + c];
   for (int r = 0; r < width_rows; ++r)
     out[(long long)(d + n_terms + r) * n_traced + t] = (double)width[(long long)r * n + c];
 }
 
 hipError_t launch_trace(const void *x, const void *energy, const void *width, long long n, int d, int n_terms,
-                        int width_rows, int dtype, long long n_traced, long long stride, double *out, hipStream_t stream) {
+                        int width_rows, int dtype, long long n_traced, long long stride, double *out, hipStream_t stream,
+                        bool tiled_state) {
   const dim3 grid((unsigned)((n_traced + kBlockThreads - 1) / kBlockThreads)), block(kBlockThreads);
   if (dtype == ME_F32)
     hipLaunchKernelGGL(k_trace<float>, grid, block, 0, stream, (const float *)x, (const float *)energy, (const float *)width,
-                       n, d, n_terms, width_rows, n_traced, stride, out);
+                       n, d, n_terms, width_rows, n_traced, stride, tiled_state ? 1 : 0, out);
   else
     hipLaunchKernelGGL(k_trace<double>, grid, block, 0, stream, (const double *)x, (const double *)energy,
-                       (const double *)width, n, d, n_terms, width_rows, n_traced, stride, out);
+                       (const double *)width, n, d, n_terms, width_rows, n_traced, stride, tiled_state ? 1 : 0, out);
   return hipGetLastError();
 }
 
@@ -295,13 +299,16 @@ int pool_reduce_blocks(long long n, int nr, int nc) {
   long long cap = (32ll << 20) / (8 * n_entries);   // at most 32 MiB of partials
   if (cap > 1024) cap = 1024;
   if (cap < 64) cap = 64;
+  // small parameter spaces (one 32-row block of augmented rows): the stage-1 kernels are whole workgroups of 8 / 16
+  // wavefronts that write ONE row each (me_pool_gram.h); one workgroup per CU
+  if (d + nr + nc <= 32) cap = 256;
   const long long tiles = (n + 63) / 64;
   return (int)(tiles < cap ? (tiles < 1 ? 1 : tiles) : cap);
 }
 
 namespace {
 template <typename R, int TILE>
-hipError_t launch_pool_stage1(const void *x, long long n, int nr, int nc, int n_entries, int blocks, double *partials, hipStream_t stream) {
+hipError_t launch_pool_stage1(const void *x, long long n, int nr, int nc, int n_entries, int blocks, double *partials, hipStream_t stream, bool tiled) {
   const size_t lds = (size_t)(nr + 2 * nc + nr + nc) * (size_t)(TILE + 1) * sizeof(R);
   if (lds > 64 * 1024) {
     static PerDevice<hipError_t> attr;
@@ -313,15 +320,16 @@ hipError_t launch_pool_stage1(const void *x, long long n, int nr, int nc, int n_
     if (rc != hipSuccess) return rc;
   }
   for (int base = 0; base < n_entries; base += kMaxEntries * kBlockThreads)
-    hipLaunchKernelGGL((k_pool_reduce<R, TILE>), dim3((unsigned)blocks), dim3(kBlockThreads), lds, stream, (const R *)x, n, nr, nc, base, partials);
+    hipLaunchKernelGGL((k_pool_reduce<R, TILE>), dim3((unsigned)blocks), dim3(kBlockThreads), lds, stream, (const R *)x, n, nr, nc, base,
+                       tiled ? 1 : 0, partials);
   return hipGetLastError();
 }
 template <typename R>
-hipError_t launch_pool_stage1_tile(int tile, const void *x, long long n, int nr, int nc, int n_entries, int blocks, double *partials, hipStream_t stream) {
+hipError_t launch_pool_stage1_tile(int tile, const void *x, long long n, int nr, int nc, int n_entries, int blocks, double *partials, hipStream_t stream, bool tiled) {
   switch (tile) {
-    case 64: return launch_pool_stage1<R, 64>(x, n, nr, nc, n_entries, blocks, partials, stream);
-    case 32: return launch_pool_stage1<R, 32>(x, n, nr, nc, n_entries, blocks, partials, stream);
-    case 16: return launch_pool_stage1<R, 16>(x, n, nr, nc, n_entries, blocks, partials, stream);
+    case 64: return launch_pool_stage1<R, 64>(x, n, nr, nc, n_entries, blocks, partials, stream, tiled);
+    case 32: return launch_pool_stage1<R, 32>(x, n, nr, nc, n_entries, blocks, partials, stream, tiled);
+    case 16: return launch_pool_stage1<R, 16>(x, n, nr, nc, n_entries, blocks, partials, stream, tiled);
     default: return hipErrorInvalidValue;
   }
 }
@@ -330,7 +338,7 @@ hipError_t launch_pool_stage1_tile(int tile, const void *x, long long n, int nr,
 hipError_t launch_pool_reduce(const void *x, long long n, int nr, int nc, int dtype, const unsigned long long *slots,
                               long long n_slots, double proposed, double *partials, double *out_device,
                               hipStream_t stream,
-                              hipError_t (*stage1)(const void *, long long, double *, int, hipStream_t)) {
+                              hipError_t (*stage1)(const void *, long long, double *, int, hipStream_t), bool tiled_state) {
   const int d = nr + 2 * nc;
   const int n_aug = d + nr + nc;
   const int n_entries = 1 + n_aug + d * (d + 1) / 2;
@@ -339,8 +347,8 @@ hipError_t launch_pool_reduce(const void *x, long long n, int nr, int nc, int dt
   const int blocks = pool_reduce_blocks(n, nr, nc);
   hipError_t err;
   if (stage1) err = stage1(x, n, partials, blocks, stream);
-  else if (dtype == ME_F32) err = launch_pool_stage1_tile<float>(tile, x, n, nr, nc, n_entries, blocks, partials, stream);
-  else err = launch_pool_stage1_tile<double>(tile, x, n, nr, nc, n_entries, blocks, partials, stream);
+  else if (dtype == ME_F32) err = launch_pool_stage1_tile<float>(tile, x, n, nr, nc, n_entries, blocks, partials, stream, tiled_state);
+  else err = launch_pool_stage1_tile<double>(tile, x, n, nr, nc, n_entries, blocks, partials, stream, tiled_state);
   if (err != hipSuccess) return err;
   hipLaunchKernelGGL(k_pool_finish, dim3((unsigned)((n_entries + 63) / 64 + 1)), dim3(kFinishThreads), 0, stream,
                      (const double *)partials, blocks, nr, nc, slots, n_slots, proposed, out_device);

@@ -123,6 +123,9 @@ struct KernelSet {
   // optional: n_sweeps x step_all + measure in ONE launch (k_cycle); nullptr or hipErrorNotSupported: me_cycle issues the
   // step launch and the measure launch instead (same results)
   hipError_t (*cycle)(const StepLaunch &, const MeasureLaunch &, hipStream_t);
+  // the kernels of this set address the chain state x TILE-major ([tile of 64 chains][D][64 lanes], me_device.h: XField)
+  // instead of component-major: the register-resident sets from kTiledStateDof real degrees of freedom on
+  bool tiled_state;
 };
 
 void register_kernel_set(const KernelSet *set);
@@ -142,7 +145,8 @@ hipError_t launch_broadcast_tiled(void *dst, const void *entry_values, int entri
 hipError_t launch_pool_reduce(const void *x, long long n, int n_real, int n_complex, int dtype,
                               const unsigned long long *slots, long long n_slots, double proposed, double *partials,
                               double *out_device, hipStream_t stream,
-                              hipError_t (*stage1)(const void *, long long, double *, int, hipStream_t) = nullptr);
+                              hipError_t (*stage1)(const void *, long long, double *, int, hipStream_t) = nullptr,
+                              bool tiled_state = false);
 // blocks of the first reduction stage; partials must hold pool_reduce_blocks(...) * (1 + D + nr + nc + D(D+1)/2) doubles
 int pool_reduce_blocks(long long n, int n_real, int n_complex);
 // false: the dimensions are beyond the pooled-moment kernels (me_pooled_moments then returns ME_ERR_UNSUPPORTED)
@@ -150,7 +154,8 @@ bool pool_reduce_supported(int n_real, int n_complex, int dtype);
 // Time-series row of the traced chains (chain t*stride, t < n_traced): out[col][t] as doubles with columns
 // [params (d) | energy terms (n_terms) | widths (width_rows)]  -- what measure() appends in the reference (:350-356).
 hipError_t launch_trace(const void *x, const void *energy, const void *width, long long n, int d, int n_terms,
-                        int width_rows, int dtype, long long n_traced, long long stride, double *out, hipStream_t stream);
+                        int width_rows, int dtype, long long n_traced, long long stride, double *out, hipStream_t stream,
+                        bool tiled_state = false);
 // total[0] = sum of slots[0 .. n_slots)
 // Batched equilibration detection (me_statistics.hip; me_detect_equilibration in the public header).
 hipError_t launch_detect_equilibration(const double *series, long long n_series, long long length, int fast, int nskip,

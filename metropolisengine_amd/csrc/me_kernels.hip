@@ -500,6 +500,7 @@ constexpr auto pool_stage1_f32() -> hipError_t (*)(const void *, long long, doub
 }
 constexpr auto pool_stage1_f64() -> hipError_t (*)(const void *, long long, double *, int, hipStream_t) {
   if constexpr (NR == 64 && NC == 0) return launch_pool_gram64_f64;
+  else if constexpr (D + NR + NC <= 32) return launch_pool_gram32_f64<NR, NC>;
   else return nullptr;
 }
 #if ME_DENSE && !defined(ME_USER_SOURCE)
@@ -539,12 +540,12 @@ constexpr bool kHasUserReject = false;
 #if ME_ONLY_DTYPE != 64
 const KernelSet kSetF32 = {ME_SET_NAME, ME_F32, NR, NC, ME_PER_CHAIN != 0, (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0), has_energy, energy_terms, step<float>,
                            (NC > 0 && ME_PER_CHAIN == 1) ? magphase<float> : nullptr, measure<float>, init_energy<float>,
-                           ME_PREPARE_MATRIX_F32, kHasUserReject, ME_PER_CHAIN == 2, cycle<float>};
+                           ME_PREPARE_MATRIX_F32, kHasUserReject, ME_PER_CHAIN == 2, cycle<float>, D >= kTiledStateDof};
 #endif
 #if ME_ONLY_DTYPE != 32
 const KernelSet kSetF64 = {ME_SET_NAME, ME_F64, NR, NC, ME_PER_CHAIN != 0, (ME_PER_CHAIN != 0 || ME_TRACK_COV != 0), has_energy, energy_terms, step<double>,
                            (NC > 0 && ME_PER_CHAIN == 1) ? magphase<double> : nullptr, measure<double>, init_energy<double>,
-                           ME_PREPARE_MATRIX_F64, kHasUserReject, ME_PER_CHAIN == 2, cycle<double>};
+                           ME_PREPARE_MATRIX_F64, kHasUserReject, ME_PER_CHAIN == 2, cycle<double>, D >= kTiledStateDof};
 #endif
 
 struct Registrar {

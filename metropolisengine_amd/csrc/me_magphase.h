@@ -55,13 +55,15 @@ __global__ void __launch_bounds__(kStepThreads) k_step_magphase(StepArgs<R> a, E
   bool bad_energy = false, bad_width = false;
   const long long stride = (long long)gridDim.x * kStepThreads;
   using Ledger = EnergyLedger<R, Energy, MIXED ? GROUP_COMPLEX : GROUP_ALL>;   // the complex group's terms (:183-189)
-  const Field<R> fx(a.x, a.n, D), fe(a.energy, a.n, Ledger::T), fw(a.width, a.n, MIXED ? 3 : 1);
+  const XField<R, D> fx(a.x, a.n);
+  const Field<R> fe(a.energy, a.n, Ledger::T), fw(a.width, a.n, MIXED ? 3 : 1);
   const TiledField<R> fcov(a.factor, a.n, P);      // the covariance field (tile-major)
   for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
+    const unsigned int xoff = fx.offset(c);
     R x[D], kdiag[NC];
 #pragma unroll
-    for (int d = 0; d < D; ++d) x[d] = fx.load(d, coff);
+    for (int d = 0; d < D; ++d) x[d] = fx.load(d, xoff);
 #pragma unroll
     for (int j = 0; j < NC; ++j) kdiag[j] = fcov.load(cdiag(PR, j), tiled_offset<R>(c, P));
     Ledger ledger;
@@ -152,7 +154,7 @@ __global__ void __launch_bounds__(kStepThreads) k_step_magphase(StepArgs<R> a, E
     }
     bad_width |= !(w > R(0));
 #pragma unroll
-    for (int d = NR; d < D; ++d) fx.store(d, coff, x[d]);
+    for (int d = NR; d < D; ++d) fx.store(d, xoff, x[d]);
     ledger.store(fe, coff);
     fw.store(WROW, coff, w);
   }

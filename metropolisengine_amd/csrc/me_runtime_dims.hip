@@ -622,9 +622,9 @@ hipError_t init_energy(const EnergyLaunch &l, hipStream_t stream) {
 
 // n_real = n_complex = -1: the wildcard set find_kernel_set falls back to above kMaxRegisterDof (me_api.hip)
 const KernelSet kRuntimeF32 = {nullptr, ME_F32, -1, -1, false, false, has_energy, energy_terms, step<float>, nullptr,
-                               measure<float>, init_energy<float>, 0, nullptr, nullptr, false, false, nullptr};
+                               measure<float>, init_energy<float>, 0, nullptr, nullptr, false, false, nullptr, false};
 const KernelSet kRuntimeF64 = {nullptr, ME_F64, -1, -1, false, false, has_energy, energy_terms, step<double>, nullptr,
-                               measure<double>, init_energy<double>, 0, nullptr, nullptr, false, false, nullptr};
+                               measure<double>, init_energy<double>, 0, nullptr, nullptr, false, false, nullptr, false};
 
 struct Registrar {
   Registrar() {
