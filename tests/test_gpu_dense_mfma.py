@@ -49,6 +49,43 @@ def test_mfma_energy_one_step_vs_oracle(matrix, temp):
     assert same.mean() > 0.99
 
 
+@pytest.mark.parametrize("shape", ["identity", "shared"])
+def test_split_bf16_kernel_50_sweep_trajectory_against_the_oracle(shape):
+    """The float32 matrix-core kernel tied DIRECTLY to the float64 oracle over a trajectory (round 2 tied it to the float64
+    kernel only): same Philox streams, 50 sweeps, a chain's accept sequence must equal the oracle's for >= 98 % of the
+    chains (the rest are near-ties of u against exp(-dE/T) that a 1e-7 relative error in dE flips), and those chains' states,
+    energies and adapted widths agree to float32 accuracy.  Identity shape and a shared proposal factor (L g on the cores)."""
+    n, seed, sweeps = 2048 + 19, 23, 50
+    x0 = list(np.linspace(-0.2, 0.2, 64))
+    kw = dict(temp=1.0, n_chains=n, seed=seed, sampling_width=0.08)
+    okw = dict(seed=seed, temp=1.0, initial_real_params=x0, sampling_width=0.08, adapt_shape=False)
+    if shape == "shared":
+        b = np.random.default_rng(9).standard_normal((64, 64))
+        cov = 0.5 * np.linalg.inv(AMAT) + 0.05 * (b @ b.T) / 64
+        eng = me.MetropolisEngine(me.DenseQuadratic(AMAT), None, x0, None, cov_mode="pooled", **kw)
+        eng.set_shared_factor(np.linalg.cholesky(cov)[np.tril_indices(64)])
+        ora = ManyChainOracle(64, 0, energies.dense_quadratic(64, 0, AMAT), n, covariance_matrix_real=cov, **okw)
+    else:
+        eng = me.MetropolisEngine(me.DenseQuadratic(AMAT), None, x0, None, cov_mode="fixed", **kw)
+        ora = ManyChainOracle(64, 0, energies.dense_quadratic(64, 0, AMAT), n, **okw)
+    same = np.ones(n, dtype=bool)
+    for _ in range(sweeps):
+        before = ora.accepted
+        eng.step_all()
+        ora.step()
+        moved_gpu = np.any(np.abs(eng._get(0) - ora.x) > 1e-3, axis=1)        # a flipped decision moves the state by ~width
+        same &= ~moved_gpu
+        assert ora.accepted >= before
+    assert same.mean() >= 0.98, same.mean()
+    x = eng._get(0)
+    assert np.max(np.abs(x[same] - ora.x[same])) < 2e-4
+    assert np.allclose(eng.energy_total[same], ora.energy[same], rtol=2e-5, atol=2e-5)
+    assert np.allclose(eng.sampling_width[same], ora.width_real[same], rtol=2e-5)
+    acc, prop = eng.accept_stats()
+    assert prop == n * sweeps and abs(acc - ora.accepted) <= 0.02 * n + 8
+    assert 0.05 < ora.accepted / ora.proposed < 0.95
+
+
 def test_mfma_stationary_covariance_identity_and_pooled():
     n = 1 << 13
     want = 0.5 * np.linalg.inv(AMAT)                        # density exp(-x^T A x / T), T = 1
