@@ -161,7 +161,9 @@ def build_user_energy(source, name, n_real, n_complex, force=False, per_chain=Tr
     source = os.path.abspath(source)
     if not name.isidentifier():
         raise ValueError("plugin name must be an identifier")
-    defines = ["-DME_NR=%d" % n_real, "-DME_NC=%d" % n_complex, "-DME_PER_CHAIN=%d" % int(per_chain),
+    packed = n_real * (n_real + 1) // 2 + n_complex * n_complex
+    defines = ["-DME_NR=%d" % n_real, "-DME_NC=%d" % n_complex,
+               "-DME_PER_CHAIN=%d" % ((1 if packed <= MAX_PACKED_IN_REGISTERS else 2) if per_chain else 0),
                "-DME_USER_SOURCE=\"%s\"" % source, "-DME_USER_NAME=\"%s\"" % name]
     # the absolute source path is part of the command line but not of the cache key: hash its basename + contents
     key_defines = defines[:3] + ["-DME_USER_SOURCE=" + os.path.basename(source), defines[4]]
@@ -194,7 +196,7 @@ def build_dims(n_real, n_complex, force=False):
                            "run on the runtime-dimension kernels of the main library (csrc/me_runtime_dims.hip), no build "
                            "needed" % (MAX_REGISTER_DOF, d))
     defines = ["-DME_NR=%d" % n_real, "-DME_NC=%d" % n_complex, "-DME_DENSE=%d" % int(d <= 24),
-               "-DME_PER_CHAIN=%d" % (1 if packed <= MAX_PACKED_IN_REGISTERS else (2 if n_complex == 0 else 0))]
+               "-DME_PER_CHAIN=%d" % (1 if packed <= MAX_PACKED_IN_REGISTERS else 2)]   # 2: packed matrices streamed
     return _build_plugin(dims_plugin_path(n_real, n_complex), defines, [], force=force)
 
 
@@ -205,10 +207,11 @@ def build_examples(force=False):
     src = os.path.join(REPO_DIR, "examples", "user_energy_cylinder.h")
     terms = os.path.join(REPO_DIR, "examples", "user_energy_landau_terms.h")
     build(verbose=False)
-    with concurrent.futures.ThreadPoolExecutor(max_workers=6) as pool:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=7) as pool:
         jobs = [pool.submit(build_user_energy, src, "cylinder", 2, 7, force), pool.submit(build_dims, 3, 2, force),
                 pool.submit(build_user_energy, terms, "landau_terms", 2, 1, force),
-                pool.submit(build_dims, 1, 13, force),     # 170 packed entries: the streaming-covariance path
+                pool.submit(build_dims, 1, 13, force),     # 170 packed entries WITH a complex block: streamed mixed shapes
+                pool.submit(build_dims, 0, 13, force),     # ... and a pure complex space beyond the register-resident size
                 pool.submit(build_dims, 24, 0, force),     # streamed per-chain shapes with two chains per wavefront
                 pool.submit(build_dims, 96, 0, force)]     # the largest register-resident parameter space
         return [job.result() for job in jobs]

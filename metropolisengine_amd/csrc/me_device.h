@@ -819,7 +819,7 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
   // the kernel needs ~100 registers and four wavefronts share a SIMD.
   constexpr bool STREAM_FACTOR = PER_CHAIN && (PF > kMaxPackedInRegisters ||
                                                (!INJECT && sizeof(R) == 8 && NC == 0 && PF > kStreamF64Entries));
-  static_assert(!STREAM_FACTOR || NC == 0, "streamed per-chain factors exist for pure real parameter spaces");
+  // (round 3: mixed and complex spaces stream too -- the complex rows follow the real triangle in the packed order)
   const TiledField<R> ffac(a.factor, a.n, STREAM_FACTOR ? 0 : PF);
   for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < a.n; c += stride) {
     const unsigned int coff = (unsigned int)c * (unsigned int)sizeof(R);
@@ -915,6 +915,18 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
 #pragma unroll
         for (int u = 0; u < CH; ++u)
           if (u < PF) f[0][u] = entry(u);
+        // entry k of the packed factor, consumed in ascending order: entering a chunk puts the one after it in flight first
+        auto use = [&](auto entry_index) -> R {
+          constexpr int k = decltype(entry_index)::value;
+          if constexpr (k % CH == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+              if (k + CH + u < PF) f[(k / CH + 1) & 1][u] = entry(k + CH + u);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          return f[(k / CH) & 1][k % CH];
+        };
         // (row and column are template constants: as `#pragma unroll` loop variables a row of 64 columns with its chunk of
         // loads passes LLVM's size limit for forced unrolling, is unrolled too late, and the arrays stay in scratch)
         static_for<NR>([&](auto row_index) {
@@ -922,16 +934,31 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
           R acc = 0;
           static_for<i + 1>([&](auto col_index) {
             constexpr int j = decltype(col_index)::value, k = tri(i, j);
-            if constexpr (k % CH == 0) {   // entering a chunk: put the one after it in flight first
-              __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-              for (int u = 0; u < CH; ++u)
-                if (k + CH + u < PF) f[(k / CH + 1) & 1][u] = entry(k + CH + u);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-            acc = j == 0 ? f[(k / CH) & 1][k % CH] * g[0] : acc + f[(k / CH) & 1][k % CH] * g[j];
+            const R l = use(std::integral_constant<int, k>{});
+            acc = j == 0 ? l * g[0] : acc + l * g[j];
           });
-          xp[i] = x[i] + w_r * acc;
+          if constexpr (GROUP != GROUP_COMPLEX) xp[i] = x[i] + w_r * acc;      // (a resting group's rows are walked, not applied)
+        });
+        // complex rows (:274-302): z'_i = z_i + w_c sum_{j <= i} L_ij (g_re_j + i g_im_j) / sqrt 2, L = chol(conj K) packed as
+        // (Re, Im) of the columns j < i, then the real diagonal -- the same arithmetic, term by term, as propose_registers
+        static_for<NC>([&](auto row_index) {
+          constexpr int i = decltype(row_index)::value;
+          R are = 0, aim = 0;
+          static_for<i>([&](auto col_index) {
+            constexpr int j = decltype(col_index)::value;
+            const R lre = use(std::integral_constant<int, cre(NR * (NR + 1) / 2, i, j)>{});
+            const R lim = use(std::integral_constant<int, cim(NR * (NR + 1) / 2, i, j)>{});
+            const R wre = g[NR + j] * R(0.70710678118654752440), wim = g[NR + NC + j] * R(0.70710678118654752440);
+            are += lre * wre - lim * wim;
+            aim += lre * wim + lim * wre;
+          });
+          const R ld = use(std::integral_constant<int, cdiag(NR * (NR + 1) / 2, i)>{});
+          are += ld * (g[NR + i] * R(0.70710678118654752440));
+          aim += ld * (g[NR + NC + i] * R(0.70710678118654752440));
+          if constexpr (GROUP != GROUP_REAL) {
+            xp[NR + i] = x[NR + i] + w_c * are;
+            xp[NR + NC + i] = x[NR + NC + i] + w_c * aim;
+          }
         });
         // ---- hard wall before the energy (:247-249), energy, accept rule (:319-338), commit, width (decide_step's code)
         bool rejected = false;
@@ -949,7 +976,9 @@ __global__ void ME_STEP_BOUNDS k_step(StepArgs<R> a, Energy en) {
         if (stale_total) total_q5 = accept ? e_new : total_q5;
         else ledger.commit(accept, terms_new);
         w = N_::adapt(w, accept, a.ratio, a.p, a.damping, a.up, a.down);
-        w_r = w_c = w;
+        if constexpr (GROUP == GROUP_ALL) w_r = w_c = w;
+        else if constexpr (GROUP == GROUP_REAL) w_r = w;
+        else w_c = w;
         wave_accepted += (unsigned int)__popcll(__ballot(accept));
       }
     } else {
@@ -1473,6 +1502,58 @@ __global__ void __launch_bounds__(kStepThreads) k_factor_stream(const R *cov, R 
       }
       // the next block reads these rows back through global memory from this same lane: program order suffices
     }
+  }
+  if (bad_pivot) atomicOr(status, (unsigned int)ST_BAD_PIVOT);
+}
+
+// Per-chain Cholesky factors of a packed matrix too large for registers that has a COMPLEX block (mixed and pure complex
+// spaces beyond 160 packed entries, e.g. 1 real + 13 complex = 170): factor = [chol(C_r) | chol(conj K)] (quirk Q3,
+// metropolis_engine.py:292-298), row by row (Cholesky-Banachiewicz), each lane its own chain, every operand through global
+// memory in the tile-major layout -- a finished L_ik is re-read from the factor field the lane itself wrote (program order
+// suffices).  Written for correctness, not speed (a dependent load per multiply-add): it exists so that
+// cov_mode="reference" keeps the reference's semantics (:416-427 feeding :274-302) for such spaces at all; the pure real
+// sizes have k_factor_tile / k_factor_stream.
+template <typename R, int NR, int NC, bool NT>
+__global__ void __launch_bounds__(kStepThreads) k_factor_mixed(const R *cov, R *factor, unsigned int *status, long long n) {
+  constexpr int PR = NR * (NR + 1) / 2, P = PR + NC * NC;
+  using N_ = Num<R>;
+  bool bad_pivot = false;
+  const long long stride = (long long)gridDim.x * kStepThreads;
+  for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < n; c += stride) {
+    const long long base = (c >> 6) * (long long)P * 64 + (c & 63);
+    const R *cv = cov + base;
+    R *fc = factor + base;
+    auto in = [&](int k) -> R { return NT ? __builtin_nontemporal_load(cv + (long long)k * 64) : cv[(long long)k * 64]; };
+    for (int i = 0; i < NR; ++i)
+      for (int j = 0; j <= i; ++j) {
+        R s = in(tri(i, j));
+        for (int k = 0; k < j; ++k) s = fma_(-fc[(long long)tri(i, k) * 64], fc[(long long)tri(j, k) * 64], s);
+        if (j < i) {
+          fc[(long long)tri(i, j) * 64] = s / fc[(long long)tri(j, j) * 64];
+        } else {
+          if (!(s > R(0))) { bad_pivot = true; s = R(1e-30); }
+          fc[(long long)tri(i, i) * 64] = N_::sqrt_(s);
+        }
+      }
+    for (int i = 0; i < NC; ++i)
+      for (int j = 0; j <= i; ++j) {
+        R sr = j < i ? in(cre(PR, i, j)) : in(cdiag(PR, i));
+        R si = j < i ? -in(cim(PR, i, j)) : R(0);                 // conj(K)
+        for (int k = 0; k < j; ++k) {                              // s -= L_ik conj(L_jk)
+          const R ar = fc[(long long)cre(PR, i, k) * 64], ai = fc[(long long)cim(PR, i, k) * 64];
+          const R br = fc[(long long)cre(PR, j, k) * 64], bi = fc[(long long)cim(PR, j, k) * 64];
+          sr = fma_(-ai, bi, fma_(-ar, br, sr));
+          si = fma_(ar, bi, fma_(-ai, br, si));
+        }
+        if (j < i) {
+          const R d = fc[(long long)cdiag(PR, j) * 64];
+          fc[(long long)cre(PR, i, j) * 64] = sr / d;
+          fc[(long long)cim(PR, i, j) * 64] = si / d;
+        } else {
+          if (!(sr > R(0))) { bad_pivot = true; sr = R(1e-30); }
+          fc[(long long)cdiag(PR, i) * 64] = N_::sqrt_(sr);
+        }
+      }
   }
   if (bad_pivot) atomicOr(status, (unsigned int)ST_BAD_PIVOT);
 }

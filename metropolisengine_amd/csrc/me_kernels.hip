@@ -472,9 +472,12 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
     }
   }
 #elif ME_PER_CHAIN == 2
-  static_assert(NC == 0 && P > kMaxPackedInRegisters, "ME_PER_CHAIN=2 is for pure real spaces with more than 160 packed entries");
+  static_assert(P > kMaxPackedInRegisters, "ME_PER_CHAIN=2 is for spaces with more than 160 packed entries");
   if (l.cov && l.update_cov && l.write_factor) {
-    if constexpr (NR <= 64) {     // a lane group per chain, a lane per row: every matrix read once (me_factor_tile.h)
+    if constexpr (NC > 0) {       // a complex block: the plain one-lane-per-chain form (k_factor_mixed, me_device.h)
+      if (nt) hipLaunchKernelGGL((k_factor_mixed<R, NR, NC, true>), grid, block, 0, stream, (const R *)l.cov, (R *)l.factor, l.status, l.n);
+      else hipLaunchKernelGGL((k_factor_mixed<R, NR, NC, false>), grid, block, 0, stream, (const R *)l.cov, (R *)l.factor, l.status, l.n);
+    } else if constexpr (NR <= 64) {     // a lane group per chain, a lane per row: every matrix read once (me_factor_tile.h)
       const hipError_t err = nt ? launch_factor_tile<R, NR, true>((const R *)l.cov, (R *)l.factor, l.status, l.n, stream)
                                 : launch_factor_tile<R, NR, false>((const R *)l.cov, (R *)l.factor, l.status, l.n, stream);
       if (err != hipSuccess) return err;

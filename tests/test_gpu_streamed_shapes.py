@@ -126,3 +126,49 @@ def test_fixed_and_pooled_shapes_at_64_parameters_keep_no_per_chain_matrices():
     eng.measure()
     with pytest.raises(NotImplementedError):
         eng.covariance_matrix_real
+
+
+@pytest.mark.parametrize("nr,nc", [(1, 13), (0, 13)])
+def test_mixed_and_complex_spaces_beyond_160_entries_follow_the_oracle(nr, nc):
+    """Round 3: per-chain adaptive shapes for spaces WITH a complex block beyond the register-resident size (1 real + 13
+    complex = 170 packed entries; 13 complex = 169): the Hermitian covariance streams through k_measure, k_factor_mixed builds
+    chol(C_r) and chol(conj K) (quirk Q3, metropolis_engine.py:292-298), and k_step streams the complex rows of the factor
+    behind the real triangle (:274-302).  float64 against the many-chain oracle across the 50-measure threshold; the
+    group-wise steps of the mixed space stream the same factor."""
+    n, seed = 70, 43
+    a, b = tuple([0.7] * nr), tuple(0.5 + 0.25 * j for j in range(nc))
+    real0 = [0.1] * nr if nr else None
+    cplx0 = [0.05 * (j + 1) * np.exp(0.3j * j) for j in range(nc)]
+    eng = me.MetropolisEngine(me.DiagQuadratic(a, b), None, real0, cplx0, temp=1.0, n_chains=n, seed=seed, dtype="f64",
+                              sampling_width=0.2)
+    ora = ManyChainOracle(nr, nc, energies.diag_quadratic(nr, nc, a, b), n, seed=seed, temp=1.0, initial_real_params=real0,
+                          initial_complex_params=cplx0, sampling_width=0.2)
+    assert eng.cov_mode == "reference"
+    for _ in range(56):
+        eng.step_all(3)
+        ora.step(3)
+        eng.measure()
+        ora.measure()
+    assert np.abs(ora.cov_complex[0] - np.identity(nc)).max() > 1e-3          # the shapes really left the identity
+    assert np.allclose(eng.covariance_matrix_complex, ora.cov_complex, rtol=0, atol=1e-9)
+    fr, fc = eng.proposal_factors()
+    assert np.allclose(fc, ora.factor_complex, rtol=0, atol=1e-8)
+    assert np.allclose(fc @ np.conj(np.swapaxes(fc, 1, 2)), np.conj(ora.cov_complex), rtol=0, atol=1e-8)   # L L^H = conj K
+    if nr:
+        assert np.allclose(fr, ora.factor_real, rtol=0, atol=1e-8)
+    for sweeps in (1, 1, 3, 5):
+        eng.step_all(sweeps)
+        ora.step(sweeps)
+    assert np.allclose(eng._get(0), ora.x, rtol=0, atol=1e-8)
+    assert np.allclose(eng.energy_total, ora.energy, rtol=0, atol=1e-8)
+    assert eng.accept_stats() == (ora.accepted, ora.proposed)
+    if nr:                                          # group-wise steps of the mixed space
+        eng.step_real_group(2)
+        ora.step(2, group="real")
+        eng.step_complex_group(2)
+        ora.step(2, group="complex")
+        assert np.allclose(eng._get(0), ora.x, rtol=0, atol=1e-8)
+        assert eng.accept_stats() == (ora.accepted, ora.proposed)
+    eng.measure()
+    ora.measure()
+    assert np.allclose(eng.covariance_matrix_complex, ora.cov_complex, rtol=0, atol=1e-8)
