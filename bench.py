@@ -163,12 +163,18 @@ def other_configs(me, rank, world, device, chains_log2, reduce_max, backend, nat
     n = 1 << chains_log2
 
     def guarded(name, fn):
+        """A side measurement must not sink the headline line: an exception becomes ``{"error": ...}``.  On several ranks
+        the outcome is agreed on (a MAX over the ranks' failure flags), so that every rank records the block the same
+        way; failures here are deterministic across ranks (unsupported shape, out of memory), raised before the block's
+        first collective."""
+        failed, result = 0.0, None
         try:
-            out[name] = fn()
-        except Exception as exc:                        # a side measurement must not sink the headline line
-            if world > 1:
-                raise                                   # ... but on several ranks a lone failure would deadlock the others
-            out[name] = {"error": repr(exc)}
+            result = fn()
+        except Exception as exc:
+            failed, result = 1.0, {"error": repr(exc)}
+        if reduce_max(failed) > 0.0 and failed == 0.0:
+            result = {"error": "failed on another rank"}
+        out[name] = result
 
     def protocol(engine, n_chains, steps_per_measure, cycles, warm_cycles):
         protocols.cycle_protocol(engine, warm_cycles, steps_per_measure, "none", fused=True)
@@ -348,11 +354,11 @@ def main():
 
     n_local = 1 << args.chains_log2
     # rehearsal ranks share GPU 0: RCCL refuses two ranks on one device, the gloo group carries the moments there
-    pool_backend = "rccl-native" if (args.pool_backend == "native" and not rehearsal) else None
+    pool = {"backend": "rccl-native" if (args.pool_backend == "native" and not rehearsal) else None, "fallback": None}
 
     def native_comm(eng):
         """Give ``eng`` its RCCL communicator over all ranks (unique id broadcast through the process group)."""
-        if pool_backend == "rccl-native":
+        if pool["backend"] == "rccl-native":
             init_native_comm(eng, world_size=world)
 
     def make_engine(dtype, chains_log2=args.chains_log2, **extra):
@@ -421,7 +427,25 @@ def main():
 
     # the one collective: the all-reduce of the pooled moments -- through the engine's own RCCL communicator
     # (me_comm_init_rank + me_pooled_moments_allreduce, no PyTorch in the data path) unless --pool-backend torch
-    native_comm(engine)
+    # The first communicator decides the backend for the whole run, collectively: if it cannot be created on ANY rank
+    # (librccl missing, an id that does not arrive) every rank falls back to torch.distributed, and the line says so.
+    if pool["backend"] == "rccl-native":
+        ok, why = 1.0, None
+        try:
+            native_comm(engine)
+        except Exception as exc:
+            ok, why = 0.0, repr(exc)
+        if distributed:
+            flag = torch.tensor([ok], dtype=torch.float64, device=comm_device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = float(flag[0])
+        if ok < 1.0:
+            pool["backend"], pool["fallback"] = None, why or "another rank could not create its RCCL communicator"
+            try:
+                engine.comm_destroy()
+            except Exception:
+                pass
+    pool_backend = pool["backend"]
     stats = pooled_statistics(engine, backend=pool_backend)
     rccl_version = engine.comm_info()[2] if pool_backend == "rccl-native" else None
     engine.sync()
@@ -494,6 +518,7 @@ def main():
             "multi_gpu": {"backend": backend, "ranks_seen_by_allreduce": ranks_seen, "chain_offsets": offsets,
                           "pooled_chains": stats["n_chains"],
                           "pooled_moments_backend": pool_backend or "torch.distributed", "rccl_version": rccl_version,
+                          "native_comm_fallback": pool["fallback"],
                           "ranks_seen_by_pooled_allreduce": int(round(stats["n_chains"] / float(n_local)))},
             "acceptance_rate": stats["acceptance_rate"],
             "pooled_variance_mean": float(sum(stats["covariance"][i][i] for i in range(N_REAL)) / N_REAL),
