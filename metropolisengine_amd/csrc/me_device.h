@@ -1111,14 +1111,40 @@ __device__ __forceinline__ void cholesky_packed(R (&m)[NR * (NR + 1) / 2 + NC * 
 // resident in the Infinity Cache between launches no longer fit together with it.  Measured at 2^20 x (16,0): packed
 // fields nt 468 -> 375 us, means nt on top of that 375 -> 410 us (x + means + observables = 256 MB still profit from the
 // cache); at 2^19 x (64,0), means only: 225 -> 190 us with nt (537 MB: keeping x resident for the next k_step wins).
+// Where measure_chain takes the running mean, the observable means and the packed covariance from: memory, when it asks
+// (k_measure), or registers that were loaded BEFORE the sweeps of a cycle (k_cycle: the loads travel while the sweeps run).
+template <typename R, bool NT, bool NTM>
+struct MeasureFromMemory {
+  const Field<R> &fmean, &fobs;
+  const TiledField<R> &fcov;
+  unsigned int coff, toff;
+  __device__ __forceinline__ R mean(int d) const { return packed_load<NTM>(fmean, d, coff); }
+  __device__ __forceinline__ R obs(int k) const { return packed_load<NTM>(fobs, k, coff); }
+  __device__ __forceinline__ R cov(int k) const { return packed_load<NT>(fcov, k, toff); }
+};
+// LEVEL 1: mean and observables preloaded, covariance from memory; LEVEL 2: everything preloaded
+template <typename R, int D, int NOBS, int P, int LEVEL, bool NT>
+struct MeasurePreloaded {
+  R mu[D], ob[NOBS], cv[LEVEL >= 2 ? P : 1];
+  const TiledField<R> &fcov;
+  unsigned int toff;
+  __device__ __forceinline__ R mean(int d) const { return mu[d]; }
+  __device__ __forceinline__ R obs(int k) const { return ob[k]; }
+  __device__ __forceinline__ R cov(int k) const {
+    if constexpr (LEVEL >= 2) return cv[k];
+    else return packed_load<NT>(fcov, k, toff);
+  }
+};
+
 // measure() of ONE chain whose state x is in registers: running mean (:404-410), observables (:458-463, :412-414),
 // covariance recursion (:416-427, one-pass form above) and the refresh of the chain's proposal factors.  Shared by
 // k_measure (loads x) and k_cycle (x comes straight out of the sweeps); forced inline.  widths(w_real, w_cplx) supplies
 // the group widths of the epsilon term (:418, :425) -- a field load in k_measure, registers in k_cycle.
-template <typename R, int NR, int NC, bool PER_CHAIN_COV, bool FUSED, bool NT, bool NTM, class WidthFn>
-__device__ __forceinline__ void measure_chain(const MeasureArgs<R> &a, long long c, const R (&x)[NR + 2 * NC], const Field<R> &fmean,
-                                              const Field<R> &fobs, const TiledField<R> &fcov, const TiledField<R> &ffac,
-                                              [[maybe_unused]] R (*s_delta)[kStepThreads], WidthFn &&widths, bool &bad_pivot) {
+template <typename R, int NR, int NC, bool PER_CHAIN_COV, bool FUSED, bool NT, bool NTM, class Source, class WidthFn>
+__device__ __forceinline__ void measure_chain(const MeasureArgs<R> &a, long long c, const R (&x)[NR + 2 * NC], const Source &src,
+                                              const Field<R> &fmean, const Field<R> &fobs, const TiledField<R> &fcov,
+                                              const TiledField<R> &ffac, [[maybe_unused]] R (*s_delta)[kStepThreads],
+                                              WidthFn &&widths, bool &bad_pivot) {
   constexpr int D = NR + 2 * NC;
   constexpr int PR = NR * (NR + 1) / 2;
   constexpr int P = PR + NC * NC;
@@ -1134,7 +1160,7 @@ __device__ __forceinline__ void measure_chain(const MeasureArgs<R> &a, long long
   {
     R mu[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) mu[d] = packed_load<NTM>(fmean, d, coff);
+    for (int d = 0; d < D; ++d) mu[d] = src.mean(d);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       if constexpr (STREAM) s_delta[d][threadIdx.x] = x[d] - mu[d];   // parked in LDS, see the streaming path below
@@ -1149,7 +1175,7 @@ __device__ __forceinline__ void measure_chain(const MeasureArgs<R> &a, long long
     R m[kBatch];
 #pragma unroll
     for (int u = 0; u < kBatch; ++u)
-      if (k0 + u < NOBS) m[u] = packed_load<NTM>(fobs, k0 + u, coff);
+      if (k0 + u < NOBS) m[u] = src.obs(k0 + u);
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
       const int k = k0 + u;
@@ -1234,7 +1260,7 @@ __device__ __forceinline__ void measure_chain(const MeasureArgs<R> &a, long long
       // the packed matrix is read whole, then updated and written back (FUSED keeps it for the Cholesky anyway)
       R m[P];
 #pragma unroll
-      for (int k = 0; k < P; ++k) m[k] = packed_load<NT>(fcov, k, toff);
+      for (int k = 0; k < P; ++k) m[k] = src.cov(k);
 #pragma unroll
       for (int i = 0; i < NR; ++i)
 #pragma unroll
@@ -1297,7 +1323,8 @@ __global__ void __launch_bounds__(kStepThreads, ME_MEASURE_WAVES) k_measure(Meas
     R x[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) x[d] = fx.load(d, xoff);
-    measure_chain<R, NR, NC, PER_CHAIN_COV, FUSED, NT, NTM>(a, c, x, fmean, fobs, fcov, ffac, s_delta, [&](R &w_real, R &w_cplx) {
+    const MeasureFromMemory<R, NT, NTM> src{fmean, fobs, fcov, coff, tiled_offset<R>(c, P)};
+    measure_chain<R, NR, NC, PER_CHAIN_COV, FUSED, NT, NTM>(a, c, x, src, fmean, fobs, fcov, ffac, s_delta, [&](R &w_real, R &w_cplx) {
       constexpr bool MIXED = NR > 0 && NC > 0;
       w_real = fw.load((MIXED && a.split_widths) ? 1 : 0, coff);
       w_cplx = fw.load((MIXED && a.split_widths) ? 2 : 0, coff);
@@ -1316,6 +1343,15 @@ __global__ void __launch_bounds__(kStepThreads, ME_MEASURE_WAVES) k_measure(Meas
 // CK: CK_IDENTITY / CK_SHARED (before the 50th measure, or cov_mode fixed / pooled) or CK_PER_CHAIN (each chain's own
 // factor, read once per launch).  NT / NTM: cache policy of the packed fields / the running means, as in k_measure; NT
 // also covers the factor read of the sweeps.  Packed matrices up to kMaxPackedInRegisters entries.
+// Measured (profiles/r03_cycle_prefetch_variants.txt, 10 sweeps per cycle, per-chain factors live): level 0 / 1 / 2 at (4,4) x
+// 2^20 chains 150 / 149 / 155 us (float32), 353 / 354 / 499 us (float64); at (2,7) x 2^18 chains 70 / 70 / 70 us, 185 / 192 /
+// 187 us -- with ten sweeps between the state loads and the measure half the launch is bound by the sweeps' instructions,
+// and the registers the preloaded values occupy cost more than their latency.  Default: off.
+#ifndef ME_CYCLE_PREFETCH
+#define ME_CYCLE_PREFETCH 0       // 0 / 1 / 2 (experiments)
+#endif
+constexpr int cycle_prefetch_level(int, int, int, int) { return ME_CYCLE_PREFETCH; }
+
 template <typename R, int NR, int NC, class Energy, int CK, bool NT, bool NTM>
 __global__ void ME_STEP_BOUNDS k_cycle(StepArgs<R> a, MeasureArgs<R> ma, Energy en) {
   constexpr int D = NR + 2 * NC;
@@ -1361,6 +1397,22 @@ __global__ void ME_STEP_BOUNDS k_cycle(StepArgs<R> a, MeasureArgs<R> ma, Energy 
       if constexpr (CK == CK_PER_CHAIN) return packed_load<NT>(ffac, k, toff);
       else return a.factor[k];
     };
+    // what the measure half needs from memory is requested BEFORE the sweeps (cycle_prefetch_level: 1 = mean and observables,
+    // 2 = the packed covariance too): the loads travel while the sweeps run instead of after them
+    constexpr int kPrefetch = cycle_prefetch_level(D, NOBS, P, (int)sizeof(R));
+    MeasurePreloaded<R, D, NOBS, P, kPrefetch, NT> pre{{}, {}, {}, fcov, toff};
+    if constexpr (kPrefetch >= 1) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) pre.mu[d] = packed_load<NTM>(fmean, d, coff);
+#pragma unroll
+      for (int k = 0; k < NOBS; ++k) pre.ob[k] = packed_load<NTM>(fobs, k, coff);
+    }
+    if constexpr (kPrefetch >= 2) {
+      if (ma.update_cov) {
+#pragma unroll
+        for (int k = 0; k < P; ++k) pre.cv[k] = packed_load<NT>(fcov, k, toff);
+      }
+    }
     run_sweeps<R, NR, NC, Energy, CKX, false, GROUP_ALL>(a, en, c, gid, stale_total, x, ledger, total_q5, w, w_r, w_c, fac,
                                                          wave_accepted, bad_energy);
     bad_width |= !(w > R(0));
@@ -1372,8 +1424,14 @@ __global__ void ME_STEP_BOUNDS k_cycle(StepArgs<R> a, MeasureArgs<R> ma, Energy 
     else ledger.store(fe, coff);
     fw.store(0, coff, w);
     // after a step_all both group widths equal the shared width (:436-437): that is what the epsilon terms use
-    measure_chain<R, NR, NC, true, true, NT, NTM>(ma, c, x, fmean, fobs, fcov, ffac, nullptr,
-                                                  [&](R &w_real, R &w_cplx) { w_real = w_cplx = w; }, bad_pivot);
+    if constexpr (kPrefetch >= 1) {
+      measure_chain<R, NR, NC, true, true, NT, NTM>(ma, c, x, pre, fmean, fobs, fcov, ffac, nullptr,
+                                                    [&](R &w_real, R &w_cplx) { w_real = w_cplx = w; }, bad_pivot);
+    } else {
+      const MeasureFromMemory<R, NT, NTM> src{fmean, fobs, fcov, coff, toff};
+      measure_chain<R, NR, NC, true, true, NT, NTM>(ma, c, x, src, fmean, fobs, fcov, ffac, nullptr,
+                                                    [&](R &w_real, R &w_cplx) { w_real = w_cplx = w; }, bad_pivot);
+    }
   }
   if ((threadIdx.x & 63) == 0 && wave_accepted) {
     unsigned long long *slot = a.accept_slots + (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
