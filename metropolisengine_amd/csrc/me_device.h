@@ -266,13 +266,16 @@ struct StateField : Field<R> {
 };
 
 // The chain state x[D] as the per-chain kernels address it.  Parameter spaces with fewer than kTiledStateDof real degrees of
-// freedom keep it component-major (x[row * n + chain]: 18-34 rows, where the layout costs nothing);
+// freedom keep it component-major (x[row * n + chain]: a handful of rows, where the layout costs nothing);
 // larger ones keep it TILE-major like the packed fields ([tile of 64 chains][D rows][64 lanes]).  Measured for 64
 // parameters in float64 at 2^19 chains (tools/dev/state_layout_probe64.hip, the geometry of k_step_dense64_f64, no
 // arithmetic): 64 rows 4 MiB apart 101-116 us, one contiguous 32 KiB block per tile 82-88 us -- a quarter of the memory
 // phase of BASELINE config 4.  The layout is a compile-time property of the kernel set (KernelSet::tiled_state); the host
 // gathers / scatters tiles in me_get / me_set; the runtime-dimension set stays component-major.
-constexpr int kTiledStateDof = 32;
+#ifndef ME_TILED_STATE_DOF
+#define ME_TILED_STATE_DOF 16     // (the 18-row state of the headline kernel gains 2-3 %: tools/dev/rows_probe_f64_tiled.hip)
+#endif
+constexpr int kTiledStateDof = ME_TILED_STATE_DOF;
 template <typename R, int D, bool NTS = false>
 struct XField {
   static constexpr bool kTiled = D >= kTiledStateDof;

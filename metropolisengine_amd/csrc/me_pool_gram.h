@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(64 * kSmallWavesF32) k_pool_gram32(const float
     const long long cc = live ? c : 0;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      const float v = x[(long long)d * n + cc];
+      const float v = x[state_index<float, D>(cc, d, n)];
       next[d] = live ? v : 0.0f;
     }
   };
@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(64 * kSmallWavesF64) k_pool_gram32_f64(const d
     const long long cc = live ? c : 0;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      const double v = x[(long long)d * n + cc];
+      const double v = x[state_index<double, D>(cc, d, n)];
       next[d] = live ? v : 0.0;
     }
   };
