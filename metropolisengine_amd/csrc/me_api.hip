@@ -493,7 +493,7 @@ int me_create(const me_config *c, me_engine **out) {
       keep_per_chain = false;
     }
     const long long rows = std::max<long long>(c->n_real + 2 * c->n_complex, 2 * c->n_real + c->n_complex);
-    if (rows * c->n_chains * esz >= limit)
+    if (rows * ((c->n_chains + 63) / 64 * 64) * esz >= limit)      // (the tile-major state is padded to whole 64-chain tiles)
       return fail(nullptr, ME_ERR_UNSUPPORTED,
                   "a per-chain field would exceed 4 GiB on this engine; shard the chains over more engines");
   }
@@ -713,6 +713,7 @@ int me_destroy(me_engine *e) {
   if (!e) return ME_ERR_INVALID;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);   // an all-reduce / copy of a reduction nobody collected
   release(e);
   return ME_OK;
 }
