@@ -48,6 +48,20 @@ def allreduce_moments(moments, group=None):
     return moments
 
 
+_SYMMETRIC_INDEX = {}      # d -> [d, d] index into the packed lower triangle (built once per size: this runs every cycle)
+
+
+def _symmetric_index(d):
+    idx = _SYMMETRIC_INDEX.get(d)
+    if idx is None:
+        idx = np.zeros((d, d), dtype=np.intp)
+        il = np.tril_indices(d)
+        idx[il] = np.arange(il[0].size)
+        idx = np.maximum(idx, idx.T)
+        _SYMMETRIC_INDEX[d] = idx
+    return idx
+
+
 def moments_to_statistics(moments, n_real, n_complex):
     """Convert raw summed moments ``(n, sum x, sum x x^T, sum obs, accepted, proposed)`` to ensemble statistics."""
     m = np.asarray(moments, dtype=np.float64)
@@ -58,10 +72,7 @@ def moments_to_statistics(moments, n_real, n_complex):
         raise ValueError("moment vector has the wrong length")
     n = m[0]
     mean = m[1:1 + d] / n
-    second = np.zeros((d, d))
-    il = np.tril_indices(d)
-    second[il] = m[1 + d:1 + d + n_pair]
-    second = second + np.tril(second, -1).T
+    second = m[1 + d:1 + d + n_pair][_symmetric_index(d)]       # the full symmetric matrix from its packed lower triangle
     cov = second / n - np.outer(mean, mean)
     obs = m[1 + d + n_pair:1 + d + n_pair + n_obs] / n
     accepted, proposed = m[-2], m[-1]

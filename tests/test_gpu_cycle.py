@@ -96,3 +96,37 @@ def test_cycle_records_the_time_series_like_measure():
         ref.step_all(3)
         ref.measure()
     assert np.array_equal(eng.trace(), ref.trace()) and eng.trace().shape[0] == 5
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_cycle_with_energy_dictionaries_two_ledger_mode_and_wall(dtype):
+    """The fused cycle keeps the energy ledger exactly as the step kernel does: the Landau toy as a term dictionary (two
+    ledger rows, metropolis_engine.py:111-116), the reference's two-ledger mode (quirk Q5: step_all decides against
+    energy_total only, :252-255) and a hard wall (:247-249) -- bitwise against step_all(k); measure(), every field."""
+    n, k = 1000, 4
+
+    def landau_terms(**kw):
+        return me.MetropolisEngine(me.LandauToy(1.0, -1.0, 0.5, terms=True), None, [0.5, 0.5], [0.3 + 0.1j], temp=0.1,
+                                   n_chains=n, seed=5, dtype=dtype, **kw)
+
+    def walled(**kw):
+        return me.MetropolisEngine(me.DiagQuadratic((0.2, 1.0), (1.0, 2.0)), me.AbsReal0AtLeast(0.4), [0.1, 0.0], [0.1j, 0.2],
+                                   temp=1.0, n_chains=n, seed=6, dtype=dtype, sampling_width=0.3, **kw)
+
+    for make, kw, fields in ((landau_terms, {}, FIELDS), (walled, {}, FIELDS),
+                             (walled, {"reference_energy_ledgers": True}, FIELDS + (_capi.FIELD_ENERGY_TOTAL,))):
+        fused, split = make(**kw), make(**kw)
+        if kw:                                   # make the two ledgers differ: group steps touch energy[term] only
+            for e in (fused, split):
+                e.step_real_group(3)
+                e.step_complex_group(2)
+        for _ in range(54):
+            fused.cycle(k)
+            split.step_all(k)
+            split.measure()
+        assert fused.fused_cycles() == 54
+        for field in fields:
+            assert np.array_equal(fused._get(field), split._get(field)), (make.__name__, kw, field)
+        assert fused.accept_stats() == split.accept_stats()
+        if make is walled:
+            assert np.all(np.abs(fused._get(0)[:, 0]) < 0.4)
