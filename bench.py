@@ -167,6 +167,11 @@ def other_configs(me, rank, world, device, chains_log2, reduce_max, backend, nat
         the outcome is agreed on (a MAX over the ranks' failure flags), so that every rank records the block the same
         way; failures here are deterministic across ranks (unsupported shape, out of memory), raised before the block's
         first collective."""
+        only = os.environ.get("METROPOLIS_BENCH_ONLY")       # dev: run only the blocks whose name matches this regex
+        if only:
+            import re
+            if not re.search(only, name):
+                return
         failed, result = 0.0, None
         try:
             result = fn()
