@@ -5,9 +5,12 @@ same constructor arguments in the same order, ``step_all()`` / ``measure()``, th
 arithmetic happens in libmetropolis_hip.so (HIP kernels, C ABI in include/metropolis_engine.h); this class only
 marshals arguments and unpacks results.  Differences from the reference, all forced by the GPU setting:
 
- * ``energy_functions`` is an :class:`~metropolisengine_amd.energy.EnergySpec`, not a Python callable;
-   ``reject_condition`` is a :class:`~metropolisengine_amd.energy.RejectSpec`.  (The reference silently drops a
-   ``reject_condition`` given to the constructor -- SURVEY.md quirk Q6; here it is honoured.)
+ * ``energy_functions`` is an :class:`~metropolisengine_amd.energy.EnergySpec` (built-in energy or a hand-written HIP device
+   function) OR, exactly as in the reference, a Python callable ``(real_params, complex_params) -> float`` / the dictionary of
+   term callables: the callable is traced once on symbolic parameters and compiled into a plugin (``pyenergy.py``; hipcc, about a
+   minute on first use, cached).  ``reject_condition`` is a :class:`~metropolisengine_amd.energy.RejectSpec` or, with a Python
+   energy, a Python predicate.  (The reference silently drops a ``reject_condition`` given to the constructor -- SURVEY.md
+   quirk Q6; here it is honoured.)
  * keyword-only extras: ``n_chains``, ``seed``, ``dtype``, ``device``, ``chain_offset``, ``cov_mode``, ``trace_chains``,
    ``trace_stride``, ``track_covariance``, ``reference_energy_ledgers`` (reproduce the reference's two energy ledgers,
    SURVEY.md quirk Q5: ``step_all`` of a mixed engine uses ``energy_total``, group steps ``energy[term]``).
@@ -80,12 +83,23 @@ class MetropolisEngine:
             print("must give list containing  at least one value for initial real or complex parameters")
             raise ValueError("no initial parameters")                                    # metropolis_engine.py:37-39
         if not isinstance(energy_functions, EnergySpec):
-            raise TypeError(
-                "energy_functions must be a metropolisengine_amd.energy.EnergySpec (IsoQuadratic, DiagQuadratic, "
-                "DenseQuadratic, LandauToy, CylinderSurrogate): a Python callable cannot be evaluated inside a HIP "
-                "kernel and this engine has no CPU fallback")
+            # the reference's own form: a Python callable (real_params, complex_params) -> float, or its dictionary of
+            # term callables (metropolis_engine.py:20, :111-116).  It is TRACED once on symbolic parameters, written out as
+            # a HIP device function and compiled around the kernels (pyenergy.py) -- there is still no CPU fallback.
+            if not (callable(energy_functions) or isinstance(energy_functions, dict)):
+                raise TypeError("energy_functions must be an EnergySpec (IsoQuadratic, DiagQuadratic, DenseQuadratic, LandauToy, "
+                                "CylinderSurrogate, UserEnergy), a callable (real_params, complex_params) -> float, or the "
+                                "reference's dictionary of term callables")
+            from .pyenergy import PythonEnergy, PythonReject
+            traced_reject = reject_condition if (reject_condition is not None and not isinstance(reject_condition, RejectSpec)) else None
+            if traced_reject is not None and not callable(traced_reject):
+                raise TypeError("reject_condition must be a RejectSpec, a callable (real_params, complex_params) -> bool, or None")
+            energy_functions = PythonEnergy(energy_functions, reject=traced_reject)
+            if traced_reject is not None:
+                reject_condition = PythonReject()
         if reject_condition is not None and not isinstance(reject_condition, RejectSpec):
-            raise TypeError("reject_condition must be a metropolisengine_amd.energy.RejectSpec or None")
+            raise TypeError("reject_condition must be a metropolisengine_amd.energy.RejectSpec or None (a Python predicate is "
+                            "accepted together with a Python energy: both are traced into one plugin)")
         if complex_sample_method not in ("magnitude-phase", "multivariate-gaussian"):
             print("complex_sample_method", complex_sample_method, "not recognized")       # :131-133
             print("defaulting to multivariate-gaussian")
@@ -296,8 +310,8 @@ class MetropolisEngine:
         self._reject_spec = reject_fct
 
     def set_energy_function(self, energy_function):
-        raise NotImplementedError("the energy is compiled into the kernels: pass the EnergySpec (single function or "
-                                  "term dictionary) to the constructor")
+        raise NotImplementedError("the energy is compiled into the kernels an engine is bound to at construction: pass the "
+                                  "energy (EnergySpec, Python callable or term dictionary) to the constructor")
 
     def initialize_energy_dict(self):
         """Re-evaluate every term of the energy ledger at the current state (metropolis_engine.py:152-155)."""

@@ -53,8 +53,8 @@ def test_argument_errors_match_the_reference():
         MetropolisEngine(energy.IsoQuadratic())
     with pytest.raises(AssertionError):                  # :92
         MetropolisEngine(energy.IsoQuadratic(), initial_real_params=[0.0], temp=-1.0)
-    with pytest.raises(TypeError):                       # Python callables cannot run on the GPU
-        MetropolisEngine(lambda r, c: r[0] ** 2, initial_real_params=[0.0])
+    with pytest.raises(TypeError):                       # neither an EnergySpec nor a callable / term dictionary
+        MetropolisEngine(42.0, initial_real_params=[0.0])
     with pytest.raises(TypeError):
         MetropolisEngine(energy.IsoQuadratic(), reject_condition=lambda r, c: False, initial_real_params=[0.0])
     with pytest.raises(ValueError):
