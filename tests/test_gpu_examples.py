@@ -38,3 +38,12 @@ def test_complex_and_real_demo(capsys):
     assert abs(eng.energy["field"] - x * y * (-a2 + 0.5 * a2 * a2)) < 1e-5
     assert abs(eng.energy["area"] - ((1 - x) ** 2 + (1 - y) ** 2)) < 1e-5
     assert "energy terms" in capsys.readouterr().out
+
+
+def test_readme_example_with_its_python_lambda(capsys):
+    single, many = _load("demo_python_energy").main(n_steps=300, ensemble=1 << 14)
+    assert single.measure_step_counter == 301 and np.shape(single.real_mean) == (1,)
+    x = many.real_params[:, 0]
+    assert abs(x.var() / 0.005 - 1.0) < 0.1 and abs(x.mean()) < 6 * np.sqrt(0.005 / (1 << 14))      # Var x = T / 2
+    assert many.fused_cycles() == 30
+    assert "ensemble of" in capsys.readouterr().out
