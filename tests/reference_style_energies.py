@@ -68,3 +68,12 @@ def wall(real_params, complex_params):                   # reject_condition: the
     return abs(real_params[0]) >= 1
 
 
+
+
+# ---- beyond 96 degrees of freedom: 100 real parameters, anisotropic well with one coupling (a user energy there compiles the
+# register-resident kernels for its own size instead of falling to the runtime-dimension set)
+WEIGHTS_100 = np.linspace(0.5, 2.0, 100)
+
+
+def hundred_parameters(real_params, complex_params):
+    return np.sum(WEIGHTS_100 * real_params ** 2) + 0.1 * real_params[0] * real_params[99]

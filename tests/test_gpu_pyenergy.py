@@ -7,8 +7,8 @@ import pytest
 
 import metropolisengine_amd as me
 from oracle.manychain import ManyChainOracle
-from reference_style_energies import (LANDAU, WELL, energy_function, landau_dictionary, landau_total, readme_energy, wall,
-                                      well_energy)
+from reference_style_energies import (LANDAU, WELL, energy_function, hundred_parameters, landau_dictionary, landau_total,
+                                      readme_energy, wall, well_energy)
 
 pytestmark = pytest.mark.gpu
 
@@ -92,3 +92,31 @@ def test_float32_and_the_one_launch_cycle_with_a_python_energy():
         assert np.array_equal(a._get(field), b._get(field)), field
     var = a._get(0).var(axis=0)
     assert np.all(np.abs(var / 0.05 - 1.0) < 0.15)                      # Var x = T / (2 const) = 0.05
+
+
+@pytest.mark.parametrize("cov_mode", ["fixed", "reference"])
+def test_python_energy_with_100_parameters(cov_mode):
+    """The reference has no limit on the number of parameters (metropolis_engine.py:41-60).  Built-in energies beyond 96 degrees
+    of freedom run on the runtime-dimension kernels; a USER energy (here traced from Python) compiles the register-resident
+    kernel set for its own size -- with cov_mode="reference" the per-chain 100 x 100 shapes stream (5 050 packed entries)."""
+    n, seed = 70, 9
+    x0 = list(np.linspace(-0.1, 0.1, 100))
+    eng = me.MetropolisEngine(hundred_parameters, None, x0, None, temp=1.0, n_chains=n, seed=seed, dtype="f64",
+                              sampling_width=0.05, cov_mode=cov_mode)
+    ora = ManyChainOracle(100, 0, vectorised(hundred_parameters, 100, 0), n, seed=seed, temp=1.0, initial_real_params=x0,
+                          sampling_width=0.05, adapt_shape=cov_mode == "reference")
+    cycles = 54 if cov_mode == "reference" else 8
+    for _ in range(cycles):
+        eng.step_all(2)
+        ora.step(2)
+        eng.measure()
+        ora.measure()
+    for sweeps in (1, 3):
+        eng.step_all(sweeps)
+        ora.step(sweeps)
+    assert np.allclose(eng._get(0), ora.x, rtol=0, atol=1e-8)
+    assert np.allclose(eng.energy_total, ora.energy, rtol=0, atol=1e-8)
+    assert eng.accept_stats() == (ora.accepted, ora.proposed)
+    if cov_mode == "reference":
+        fr, _ = eng.proposal_factors()
+        assert np.allclose(fr, ora.factor_real, rtol=0, atol=1e-8)
