@@ -28,23 +28,34 @@ with tempfile.TemporaryDirectory() as tmp:
     text = open(out).read()
 start = text.index(KERNEL + ":")
 body = text[start:text.index("s_endpgm", start)].splitlines()
-# the sweep loop: the innermost-level loop with the largest body (other loops of the kernel: the grid-stride loop around
-# it, the float64 build's table copy at the top, the slot sum at the tail)
-best = None
-for i, line in enumerate(body):
-    if "Inner Loop Header" not in line:
+# the sweep loop: the inner loop with the largest body.  The assembly annotates every basic block with the loop it belongs to
+# ("=>This Inner Loop Header" on the header, "in Loop: Header=BBn_m" on the others; the latch need not branch to the header
+# label -- it may fall through), so the body is the union of the blocks carrying one header's name.
+blocks, cur = [], None
+for line in body:
+    m = re.match(r"(\.LBB\d+_\d+):|; %bb\.(\d+):", line)
+    if m:
+        cur = {"label": (m.group(1) or "").lstrip("."), "note": line, "ops": []}
+        blocks.append(cur)
         continue
-    j = i
-    while j >= 0 and not body[j].startswith(".LBB"):
-        j -= 1
-    label = re.match(r"(\.LBB\d+_\d+):", body[j]).group(1)
-    ends = [k for k, l in enumerate(body) if k > j and re.search(r"s_c?branch\w*\s+" + re.escape(label) + r"\b", l)]
-    if ends and (best is None or ends[-1] - j > best[1] - best[0]):
-        best = (j, ends[-1])
+    if cur is None:
+        continue
+    text = line.strip()
+    if text.startswith(";"):
+        cur["note"] += " " + text
+    elif text and not text.startswith("."):
+        cur["ops"].append(text.split()[0])
+best = None
+for b in blocks:
+    if "Inner Loop Header" not in b["note"] or not b["label"]:
+        continue
+    members = [b] + [o for o in blocks if o is not b and re.search(r"Header=" + re.escape(b["label"][1:]) + r"\b", o["note"])]
+    ops = [op for blk in members for op in blk["ops"]]
+    if best is None or len(ops) > len(best):
+        best = ops
 if best is None:
     sys.exit("no inner loop found")
-head, end = best
-loop = [line.split()[0] for line in body[head:end + 1] if line.strip() and not line.strip().startswith((";", "."))]
+loop = best
 valu = [op for op in loop if op.startswith("v_")]
 salu = [op for op in loop if op.startswith("s_") and not op.startswith(("s_waitcnt", "s_nop", "s_cbranch"))]
 mem = [op for op in loop if op.startswith(("buffer_", "global_", "ds_", "scratch_", "flat_"))]
