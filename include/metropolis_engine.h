@@ -173,6 +173,12 @@ int me_cycle_stats(me_engine *engine, uint64_t *fused_cycles);
 /* set_reject_condition (metropolis_engine.py:142-146): the wall predicate is a launch parameter and may be changed
  * between steps (in the reference this setter is the only working way to install one, quirk Q6). */
 int me_set_reject_condition(me_engine *engine, int32_t reject_kind, double reject_bound);
+/* set_energy_function (metropolis_engine.py:134-138): bind the engine to another energy of the SAME parameter space -- a
+ * built-in kind (except ME_ENERGY_DENSE_QUAD) or a loaded user plugin -- re-collect the energy terms (the ledger is resized
+ * when their number changes) and re-evaluate every term at the current state (initialize_energy_dict, :152-155).  The
+ * chain state, widths, running statistics and counters stay.  Synchronous. */
+int me_set_energy(me_engine *engine, int32_t energy_kind, const double *energy_coeffs, int32_t n_energy_coeffs,
+                  const char *user_energy_name);
 /* Test hook (float64 engines): the same step with the random draws supplied by the caller instead of Philox --
  * for the Gaussian kinds normals [n_sweeps][n_chains][D] standard normals and uniforms [n_sweeps][n_chains][1] accept
  * draws; for ME_STEP_COMPLEX_MAGNITUDE_PHASE normals [n_sweeps][n_chains][nc] and uniforms [n_sweeps][n_chains][nc+2]

@@ -52,6 +52,7 @@ SYMBOLS = {
     "me_cycle_stats": (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_uint64)]),
     "me_step_kind": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32]),
     "me_set_reject_condition": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_double]),
+    "me_set_energy": (ctypes.c_int, [_H, ctypes.c_int32, _dp, ctypes.c_int32, ctypes.c_char_p]),
     "me_step_injected": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32, _dp, _dp]),
     "me_field_components": (ctypes.c_int, [_H, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
     "me_energy_terms": (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),

@@ -701,6 +701,58 @@ int me_set_reject_condition(me_engine *e, int32_t reject_kind, double reject_bou
   return ME_OK;
 }
 
+int me_set_energy(me_engine *e, int32_t energy_kind, const double *coeffs, int32_t n_coeffs, const char *user_name) {
+  if (!e) return ME_ERR_INVALID;
+  if (n_coeffs < 0 || (n_coeffs > 0 && !coeffs)) return fail(e, ME_ERR_INVALID, "energy coefficients missing");
+  if (e->ks->n_real < 0) return fail(e, ME_ERR_UNSUPPORTED, "me_set_energy: not available on the runtime-dimension kernel set");
+  if (energy_kind == ME_ENERGY_DENSE_QUAD)
+    return fail(e, ME_ERR_UNSUPPORTED, "me_set_energy: the dense quadratic form keeps device images of its matrix; create a new engine");
+  const KernelSet *ks = find_kernel_set(e->dtype, e->nr, e->nc, energy_kind, user_name);
+  if (!ks || ks->n_real < 0)
+    return fail(e, ME_ERR_UNSUPPORTED, is_user_kind(energy_kind)
+                    ? std::string("no user-energy plugin named '") + (user_name ? user_name : "") + "' is loaded for these dimensions"
+                    : "energy kind " + std::to_string(energy_kind) + " is not compiled for these dimensions");
+  // the engine's fields were laid out for the kernel set it was created with: the new set must use them the same way
+  if (ks->tiled_state != e->ks->tiled_state || ks->per_chain_cov != e->ks->per_chain_cov || ks->streams_packed != e->ks->streams_packed ||
+      ks->tracks_cov != e->ks->tracks_cov)
+    return fail(e, ME_ERR_UNSUPPORTED, "me_set_energy: the plugin was built with other per-chain covariance options than this engine's kernel set");
+  if (e->reject_kind == ME_REJECT_USER && !ks->has_user_reject)
+    return fail(e, ME_ERR_UNSUPPORTED, "me_set_energy: the engine's wall is the plugin's me_user_reject, which the new energy does not define");
+  const int n_terms = ks->energy_terms(energy_kind);
+  ME_HIP(e, hipSetDevice(e->device));
+  ME_HIP(e, hipStreamSynchronize(e->stream));
+  if (n_terms != e->n_terms) {      // another number of ledger rows (metropolis_engine.py:134-138: the term names are collected anew)
+    void *ledger = nullptr;
+    ME_HIP(e, hipMalloc(&ledger, (size_t)e->n * (size_t)(n_terms + (e->stale_total ? 1 : 0)) * e->esize));
+    (void)hipFree(e->energy);
+    e->energy = ledger;
+    e->n_terms = n_terms;
+    if (e->trace_chains > 0) {       // the recorded series has one column per term: it starts over
+      if (e->trace_dev) (void)hipFree(e->trace_dev);
+      e->trace_dev = nullptr;
+      e->trace_rows = e->trace_capacity = 0;
+    }
+  }
+  e->coef.assign(coeffs, coeffs + n_coeffs);
+  if (e->coef_dev) {
+    (void)hipFree(e->coef_dev);
+    e->coef_dev = nullptr;
+  }
+  if (is_user_kind(energy_kind) && !e->coef.empty()) {
+    std::vector<unsigned char> bytes;
+    to_device_type(e->coef.data(), e->coef.size(), e->dtype, bytes);
+    ME_HIP(e, hipMalloc(&e->coef_dev, bytes.size()));
+    ME_HIP(e, hipMemcpy(e->coef_dev, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+  }
+  e->ks = ks;
+  e->energy_kind = energy_kind;
+  // every term of the ledger at the current state (initialize_energy_dict, :152-155)
+  const int rc = me_recompute_energy(e);
+  if (rc != ME_OK) return rc;
+  ME_HIP(e, hipStreamSynchronize(e->stream));
+  return check_status(e);
+}
+
 int me_load_plugin(const char *path) {
   if (!path) return fail(nullptr, ME_ERR_INVALID, "null plugin path");
   // the plugin's static initialiser registers its kernel sets (me::register_kernel_set)

@@ -301,17 +301,48 @@ class MetropolisEngine:
     # ------------------------------------------------------------------ setters (:136-149)
     def set_reject_condition(self, reject_fct):
         """metropolis_engine.py:142-146 (in the reference the only working way to install a constraint, quirk Q6).
-        ``reject_fct`` is a :class:`~metropolisengine_amd.energy.RejectSpec` or ``None`` (no constraint)."""
+        ``reject_fct`` is a :class:`~metropolisengine_amd.energy.RejectSpec`, ``None`` (no constraint) or -- on an engine whose
+        energy is a Python callable -- a Python predicate ``(real_params, complex_params) -> bool``: energy and predicate are
+        traced into one new plugin and the engine is re-bound to it."""
         if reject_fct is not None and not isinstance(reject_fct, RejectSpec):
-            raise TypeError("reject_condition must be a metropolisengine_amd.energy.RejectSpec or None")
+            from .pyenergy import PythonEnergy, PythonReject
+            if not callable(reject_fct):
+                raise TypeError("reject_condition must be a RejectSpec, a callable or None")
+            if not isinstance(self._energy_spec, PythonEnergy):
+                raise TypeError("a Python reject_condition needs a Python energy (both are traced into one device plugin); "
+                                "with a built-in energy use a RejectSpec such as AbsReal0AtLeast")
+            self._bind_energy(PythonEnergy(self._energy_spec.energy, reject=reject_fct))
+            reject_fct = PythonReject()
         kind = reject_fct.kind if reject_fct is not None else _capi.REJECT_NONE
         bound = reject_fct.bound if reject_fct is not None else 0.0
         self._check(self._lib.me_set_reject_condition(self._handle, int(kind), float(bound)))
         self._reject_spec = reject_fct
 
+    def _bind_energy(self, spec):
+        nr, nc = self.num_real_params, self.num_complex_params
+        name = None
+        if hasattr(spec, "ensure_loaded"):
+            spec.ensure_loaded(nr, nc)
+            name = spec.name.encode()
+        coeffs = np.ascontiguousarray(spec.coefficients(nr, nc), dtype=np.float64)
+        self._check(self._lib.me_set_energy(self._handle, int(spec.kind), _as_double_ptr(coeffs), int(coeffs.size), name))
+        self._energy_spec = spec
+        self._user_name = name
+        self.energy_term_names = list(spec.term_names)
+
     def set_energy_function(self, energy_function):
-        raise NotImplementedError("the energy is compiled into the kernels an engine is bound to at construction: pass the "
-                                  "energy (EnergySpec, Python callable or term dictionary) to the constructor")
+        """metropolis_engine.py:134-138: replace the energy -- the reference's term dictionary, a single callable, or an
+        :class:`~metropolisengine_amd.energy.EnergySpec` -- on the same parameter space.  The term names are collected anew
+        and, unlike the reference (which leaves ``self.energy`` stale until ``initialize_energy_dict`` is called), every
+        term is re-evaluated at the current state.  State, widths, running statistics and counters stay."""
+        if not isinstance(energy_function, EnergySpec):
+            if not (callable(energy_function) or isinstance(energy_function, dict)):
+                raise TypeError("energy_function must be an EnergySpec, a callable or a dictionary of term callables")
+            from .pyenergy import PythonEnergy
+            keep = getattr(self._energy_spec, "reject", None) if isinstance(self._reject_spec, RejectSpec) and \
+                self._reject_spec.kind == _capi.REJECT_USER else None
+            energy_function = PythonEnergy(energy_function, reject=keep)
+        self._bind_energy(energy_function)
 
     def initialize_energy_dict(self):
         """Re-evaluate every term of the energy ledger at the current state (metropolis_engine.py:152-155)."""

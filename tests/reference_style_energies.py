@@ -77,3 +77,19 @@ WEIGHTS_100 = np.linspace(0.5, 2.0, 100)
 
 def hundred_parameters(real_params, complex_params):
     return np.sum(WEIGHTS_100 * real_params ** 2) + 0.1 * real_params[0] * real_params[99]
+
+
+# ---- for the setters (set_energy_function / set_reject_condition, metropolis_engine.py:134-146)
+def stiffer_well(real_params, complex_params):
+    return 2.0 * energy_function(*real_params)
+
+
+def narrow_wall(real_params, complex_params):
+    return abs(real_params[0]) >= 0.05
+
+
+# (energy, n_real, n_complex, reject) of every plugin the examples and tests construct: built by __graft_entry__.build()
+PLUGINS = (
+    (readme_energy, 1, 0, None), (well_energy, 2, 0, None), (landau_dictionary(), 2, 1, wall), (hundred_parameters, 100, 0, None),
+    (stiffer_well, 1, 0, None), (readme_energy, 1, 0, narrow_wall), (landau_total, 2, 1, None), (landau_dictionary(), 2, 1, None),
+)

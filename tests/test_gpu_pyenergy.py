@@ -8,7 +8,7 @@ import pytest
 import metropolisengine_amd as me
 from oracle.manychain import ManyChainOracle
 from reference_style_energies import (LANDAU, WELL, energy_function, hundred_parameters, landau_dictionary, landau_total,
-                                      readme_energy, wall, well_energy)
+                                      narrow_wall, readme_energy, stiffer_well, wall, well_energy)
 
 pytestmark = pytest.mark.gpu
 
@@ -120,3 +120,49 @@ def test_python_energy_with_100_parameters(cov_mode):
     if cov_mode == "reference":
         fr, _ = eng.proposal_factors()
         assert np.allclose(fr, ora.factor_real, rtol=0, atol=1e-8)
+
+
+def test_set_energy_function_and_set_reject_condition():
+    """The reference's setters (metropolis_engine.py:134-146) on a live engine: another Python energy on the same parameter
+    space (the ledger is re-evaluated at the current state), a Python wall installed after construction (the reference's only
+    working way, quirk Q6), a term dictionary replacing a single function (one ledger row becomes two), and built-in kinds."""
+    n = 64
+    eng = me.MetropolisEngine(readme_energy, initial_real_params=[0.0], temp=.01, n_chains=n, seed=5, dtype="f64")
+    ora = ManyChainOracle(1, 0, vectorised(readme_energy, 1, 0), n, seed=5, temp=.01, initial_real_params=[0.0])
+    _follow(eng, ora, 5, 3)
+    eng.set_energy_function(stiffer_well)
+    ora.energy_fn = vectorised(stiffer_well, 1, 0)
+    ora.energy = ora.energy_fn(ora.x)
+    assert np.allclose(eng.energy_total, 2.0 * eng._get(0)[:, 0] ** 2, atol=1e-14)          # re-evaluated, not stale
+    _follow(eng, ora, 5, 3)
+    eng.set_energy_function(readme_energy)
+    ora.energy_fn = vectorised(readme_energy, 1, 0)
+    ora.energy = ora.energy_fn(ora.x)
+    eng.set_reject_condition(narrow_wall)
+    ora.reject_fn = vectorised_reject(narrow_wall, 1, 0)
+    _follow(eng, ora, 20, 3)
+    assert np.all(np.abs(eng._get(0)[:, 0]) < 0.05) and np.any(np.abs(eng._get(0)[:, 0]) > 0.03)
+    eng.set_reject_condition(None)
+    ora.reject_fn = None
+    _follow(eng, ora, 5, 3)
+
+    # a single function -> the demo's term dictionary: the ledger grows from one row to two, the names follow
+    mixed = me.MetropolisEngine(landau_total, None, [0.2, 0.3], [0.1 + 0.1j], temp=0.1, n_chains=n, seed=6, dtype="f64")
+    mixed.step_all(5)
+    assert mixed.energy_term_names == ["total"]
+    total = mixed.energy_total
+    mixed.set_energy_function(landau_dictionary())
+    assert mixed.energy_term_names == ["area", "field"] and set(mixed.energy) == {"area", "field"}
+    assert np.allclose(mixed.energy["area"] + mixed.energy["field"], total, atol=1e-12)
+    mixed.step_real_group(2)
+    mixed.step_all(2)
+    mixed.measure()
+
+    # built-in kinds through the same C entry point
+    built = me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.1, 0.2], None, temp=1.0, n_chains=n, seed=7, dtype="f64")
+    built.step_all(3)
+    built.set_energy_function(me.DiagQuadratic((1.0, 3.0)))
+    x = built._get(0)
+    assert np.allclose(built.energy_total, x[:, 0] ** 2 + 3.0 * x[:, 1] ** 2, atol=1e-14)
+    with pytest.raises(TypeError):
+        built.set_reject_condition(narrow_wall)               # a Python predicate needs a Python energy
