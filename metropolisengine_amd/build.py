@@ -34,7 +34,11 @@ KERNEL_DIMS = [
     (1, 1, 0, 1), (1, 2, 0, 1), (2, 1, 0, 1), (2, 2, 1, 1), (4, 4, 0, 1), (2, 7, 0, 1),
 ]
 MAX_PACKED_IN_REGISTERS = 160     # per-chain covariance / factor kernels keep the packed matrix in registers
-MAX_REGISTER_DOF = 96             # largest n_real + 2 n_complex the register-resident kernels are built for
+MAX_REGISTER_DOF = 96             # largest n_real + 2 n_complex the register-resident kernels are built for BY DEFAULT: beyond
+#                                   it built-in energies run on the runtime-dimension set (no build, identity / shared shape)
+MAX_COMPILED_DOF = 128            # ... unless per-chain shapes are asked for (cov_mode="reference"): up to here the kernel set of
+#                                   the space is compiled on demand after all (minutes of hipcc; float64 keeps part of a chain's
+#                                   state in scratch there), so that the reference's semantics exist beyond 96 too
 
 
 def hipcc():
@@ -191,10 +195,10 @@ def build_dims(n_real, n_complex, force=False):
     """
     d = n_real + 2 * n_complex
     packed = n_real * (n_real + 1) // 2 + n_complex * n_complex
-    if d > MAX_REGISTER_DOF:
-        raise RuntimeError("register-resident kernels support at most %d real degrees of freedom (got %d); larger spaces "
-                           "run on the runtime-dimension kernels of the main library (csrc/me_runtime_dims.hip), no build "
-                           "needed" % (MAX_REGISTER_DOF, d))
+    if d > MAX_COMPILED_DOF:
+        raise RuntimeError("register-resident kernels are compiled for at most %d real degrees of freedom (got %d); larger "
+                           "spaces run on the runtime-dimension kernels of the main library (csrc/me_runtime_dims.hip), no "
+                           "build needed, with cov_mode='fixed' or 'pooled'" % (MAX_COMPILED_DOF, d))
     defines = ["-DME_NR=%d" % n_real, "-DME_NC=%d" % n_complex, "-DME_DENSE=%d" % int(d <= 24),
                "-DME_PER_CHAIN=%d" % (1 if packed <= MAX_PACKED_IN_REGISTERS else 2)]   # 2: packed matrices streamed
     return _build_plugin(dims_plugin_path(n_real, n_complex), defines, [], force=force)
@@ -207,13 +211,14 @@ def build_examples(force=False):
     src = os.path.join(REPO_DIR, "examples", "user_energy_cylinder.h")
     terms = os.path.join(REPO_DIR, "examples", "user_energy_landau_terms.h")
     build(verbose=False)
-    with concurrent.futures.ThreadPoolExecutor(max_workers=7) as pool:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=8) as pool:
         jobs = [pool.submit(build_user_energy, src, "cylinder", 2, 7, force), pool.submit(build_dims, 3, 2, force),
                 pool.submit(build_user_energy, terms, "landau_terms", 2, 1, force),
                 pool.submit(build_dims, 1, 13, force),     # 170 packed entries WITH a complex block: streamed mixed shapes
                 pool.submit(build_dims, 0, 13, force),     # ... and a pure complex space beyond the register-resident size
                 pool.submit(build_dims, 24, 0, force),     # streamed per-chain shapes with two chains per wavefront
-                pool.submit(build_dims, 96, 0, force)]     # the largest register-resident parameter space
+                pool.submit(build_dims, 96, 0, force),     # the largest register-resident parameter space built by default
+                pool.submit(build_dims, 100, 0, force)]    # beyond it: compiled for cov_mode="reference" (per-chain shapes)
         return [job.result() for job in jobs]
 
 

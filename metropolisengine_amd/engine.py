@@ -194,11 +194,16 @@ class MetropolisEngine:
             keep.append(c_ri)
         handle = ctypes.c_void_p()
         self._handle = None
-        if (not hasattr(energy_functions, "ensure_loaded")
-                and not self._lib.me_supported(cfg.dtype, nr, nc, _capi.ENERGY_ISO_QUAD)):
-            # dimensions outside the prebuilt set: compile this (nr, nc) kernel set once (hipcc) and load it
+        if not hasattr(energy_functions, "ensure_loaded"):
             from . import build
-            _capi.check(self._lib.me_load_plugin(build.build_dims(nr, nc).encode()))
+            d = nr + 2 * nc
+            if not self._lib.me_supported(cfg.dtype, nr, nc, _capi.ENERGY_ISO_QUAD):
+                # dimensions outside the prebuilt set: compile this (nr, nc) kernel set once (hipcc) and load it
+                _capi.check(self._lib.me_load_plugin(build.build_dims(nr, nc).encode()))
+            elif build.MAX_REGISTER_DOF < d <= build.MAX_COMPILED_DOF and cov_mode == "reference":
+                # beyond 96 degrees of freedom the runtime-dimension set (no build) has no per-chain shapes: for the
+                # reference's semantics the space's own kernel set is compiled after all (streamed shapes, minutes of hipcc)
+                _capi.check(self._lib.me_load_plugin(build.build_dims(nr, nc).encode()))
         _capi.check(self._lib.me_create(ctypes.byref(cfg), ctypes.byref(handle)))
         self._handle = handle
         n_terms = ctypes.c_int32()

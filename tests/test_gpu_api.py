@@ -132,8 +132,8 @@ def test_set_reject_condition_after_construction():
 
 
 def test_largest_register_resident_dimension():
-    """96 real degrees of freedom is the largest compile-on-demand kernel set (build.MAX_REGISTER_DOF); beyond it the
-    engine refuses.  The sampler must still be right there: stationary variance T / (2 a) per coordinate."""
+    """96 real degrees of freedom is the largest kernel set built by default (build.MAX_REGISTER_DOF).  The sampler must
+    still be right there: stationary variance T / (2 a) per coordinate."""
     n, a = 1 << 12, 2.0
     eng = me.MetropolisEngine(me.IsoQuadratic(a), initial_real_params=[0.0] * 96, temp=1.0, n_chains=n, seed=31,
                               sampling_width=0.08, cov_mode="fixed")
@@ -146,8 +146,8 @@ def test_largest_register_resident_dimension():
     assert 0.15 < eng.acceptance_rate() < 0.5
     eng.measure()
     assert np.allclose(eng.real_mean[0], (x[0] + 0.0) / 2, atol=1e-6)      # mean of the initial point and the state
-    with pytest.raises(RuntimeError):
-        me.MetropolisEngine(me.IsoQuadratic(a), initial_real_params=[0.0] * 97, temp=1.0, n_chains=64)
+    with pytest.raises(RuntimeError):               # beyond build.MAX_COMPILED_DOF per-chain shapes (the default cov_mode) are refused
+        me.MetropolisEngine(me.IsoQuadratic(a), initial_real_params=[0.0] * 200, temp=1.0, n_chains=64)
 
 
 def test_split_pooled_moments_report_the_state_at_begin():

@@ -169,7 +169,7 @@ def test_pooled_moments_and_adapt_pooled_shape_beyond_75_degrees_of_freedom(nr, 
 
 def test_unsupported_combinations_fail_loudly():
     with pytest.raises(NotImplementedError, match="identity proposal shape"):
-        me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 120, None, temp=1.0, n_chains=8)      # cov_mode="reference"
+        me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 150, None, temp=1.0, n_chains=8)      # cov_mode="reference"
     with pytest.raises(NotImplementedError, match="LDS"):
         me.MetropolisEngine(me.DenseQuadratic(np.identity(700)), None, [0.0] * 700, None, temp=1.0, n_chains=8,
                             cov_mode="fixed")                                                  # x' would not fit in LDS

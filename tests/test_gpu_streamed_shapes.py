@@ -172,3 +172,29 @@ def test_mixed_and_complex_spaces_beyond_160_entries_follow_the_oracle(nr, nc):
     eng.measure()
     ora.measure()
     assert np.allclose(eng.covariance_matrix_complex, ora.cov_complex, rtol=0, atol=1e-8)
+
+
+def test_per_chain_shapes_beyond_96_degrees_of_freedom_built_in_energy():
+    """100 real parameters, built-in energy, the reference's default semantics (cov_mode="reference"): beyond 96 degrees of
+    freedom the runtime-dimension set has no per-chain shapes, so the constructor compiles the space's own kernel set (up to
+    build.MAX_COMPILED_DOF = 128; prebuilt for this test by build_examples) and the streamed-shape kernels take over."""
+    nr, n, seed = 100, 70, 51
+    x0 = list(np.linspace(-0.2, 0.2, nr))
+    weights = tuple(np.linspace(0.5, 2.0, nr))
+    eng = me.MetropolisEngine(me.DiagQuadratic(weights), None, x0, None, temp=1.0, n_chains=n, seed=seed, dtype="f64",
+                              sampling_width=0.1)
+    ora = ManyChainOracle(nr, 0, energies.diag_quadratic(nr, 0, weights, ()), n, seed=seed, temp=1.0,
+                          initial_real_params=x0, sampling_width=0.1)
+    assert eng.cov_mode == "reference"
+    for k in range(54):
+        eng.step_all(2)
+        ora.step(2)
+        eng.measure()
+        ora.measure()
+    fr, _ = eng.proposal_factors()
+    assert np.allclose(eng.covariance_matrix_real, ora.cov_real, rtol=0, atol=1e-9)
+    assert np.allclose(fr, ora.factor_real, rtol=0, atol=1e-8)
+    for sweeps in (1, 3):
+        eng.step_all(sweeps)
+        ora.step(sweeps)
+    assert np.allclose(eng._get(0), ora.x, rtol=0, atol=1e-8)
