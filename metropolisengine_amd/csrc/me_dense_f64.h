@@ -11,59 +11,69 @@
 // 1.23 / 0.60 / 1.77 ms -- the times ADD, in one wave and across two waves of a SIMD.  So it buys no flops and no
 // overlap with the Philox / Box-Muller work; it buys DENSITY: the generic k_step<double,64,0,EnergyDense> needs 4 096
 // v_fma_f64 with 4 096 scalar-loaded coefficients per chain-step and 256 live registers of state beside them, and
-// compiled to 32-49 KB of scratch per lane (16 ms per launch).  Here 160 instructions and 32 accumulator registers do
-// the product, the coefficients are 40 LDS words per lane, and nothing spills.
+// compiled to 32-49 KB of scratch per lane (16 ms per launch).  Here 80 instructions per 32 chains and 8 accumulator
+// registers do the product, the coefficients are 40 LDS words per lane, and nothing spills.
 //
 //   * Only the symmetric part of A matters to x^T A x.  T = tril(A + A^T, -1) + diag(A) is LOWER TRIANGULAR and
 //     E = x'^T (T x'), so row block mb (16 rows) of the product needs k < 16 (mb + 1) only: 4+8+12+16 = 40 k-steps of
 //     4 instead of 64, times 4 chain blocks = 160 MFMAs instead of 256.  The shared factor L is lower triangular by
 //     construction and goes through the same code (fold(L) = L).
-//   * One wavefront = one tile of 32 chains; a chain's 64 rows are split over TWO lanes (lane = chain + 32 half).  The
-//     proposals are parked in LDS as xp[row][chain] (16 KiB per wave, chain index XOR-swizzled by the row's parity so
-//     that both the MFMA B-operand reads -- lane l wants row 4 ks + (l >> 4), chain 16 nb + (l & 15) -- and the owners'
-//     column accesses are bank-conflict free).
+//   * One wavefront = one tile of 32 chains, state AND proposals in registers in the matrix instruction's own operand
+//     layout (see "geometry" below): the products read their B operands from the registers the proposals were computed
+//     in and deliver their results to the lanes that own those rows.  LDS holds the fragments of T, 1.25 KiB of exchange
+//     per wavefront and the slab the NEXT tile's rows are prefetched into.
 //   * A-operand fragments of T: image[(mb, ks)][lane] = T[16 mb + (l & 15)][4 ks + (l >> 4)], built once per engine
 //     (k_dense64_f64_fragments), 20 KiB, copied to LDS once per block.  The factor image (CK_SHARED) stays in global
-//     memory (L1/L2 resident, read through a buffer descriptor): LDS is full.
-//   * Results: lane l holds rows (l >> 4) + 4 r (r < 4) of chain 16 nb + (l & 15) of a 16 x 16 block (the float64 C/D
-//     map differs from every other MFMA's, checked in the probe).  The energy is reduced where the results are:
-//     partial dot products against xp from LDS, then an exchange through 1 KiB of LDS brings each chain's total to both
-//     of its lanes.  For L g the row blocks are produced in DESCENDING order, so that block mb of the result can
-//     overwrite rows 16 mb .. 16 mb + 15 of g in place (later blocks read only lower rows).
-//   * Two wavefronts per SIMD (8 x 17 KiB + 20 KiB of the CU's 160 KiB of LDS; <= 256 registers), and the NEXT tile's rows
-//     are loaded into a second register set while the current tile computes.  The first version gave a wavefront 64
-//     chains -- one wavefront per SIMD -- and took 162 us per one-sweep launch and 110 us per fused sweep at 2^19 chains;
-//     this one 135 and 94.  The kernel is balanced between the float64 pipe (~94 us) and HBM (~110 us for its 554 MB,
-//     measured with the arithmetic compiled out: -DME_DENSE64_F64_MEMORY_ONLY); issuing the prefetch earlier or staggering
-//     the two halves of the workgroup changed nothing (tools/dev/time_dense64_variants.py).
+//     memory (L1/L2 resident, read through a buffer descriptor).
+//   * Results: lane l holds rows (l >> 4) + 4 r (r < 4) of chain column (l & 15) of a 16 x 16 block (the float64 C/D
+//     map differs from every other MFMA's, checked in the probe).  For L g the row blocks are produced in DESCENDING order,
+//     so that block mb of the result can overwrite slots 4 mb .. 4 mb + 3 of g in place (later blocks read only lower rows).
+//   * Two wavefronts per SIMD (<= 256 registers: 64 + 64 of state and proposals).
+//
+// History and measurements (2^19 chains, one sweep per launch / per fused sweep, tools/dev/time_dense64_ramp.py):
+//   64 chains per wavefront, one wavefront per SIMD, proposals in LDS                       162 / 110 us
+//   32 chains per wavefront, a chain's rows over two lanes, proposals in LDS (16 KiB per
+//   wavefront), next tile prefetched into a second register set                             135 /  94 us
+//   ... tile-major state                                                                    128 /  97 us
+//   this version (registers only, 16-byte accesses, prefetch by buffer_load ... lds)        125 /  92 us
+// What bounds the one-sweep launch (profiles/r03_dense64_f64_register_tiles.txt): with loads and stores compiled out it
+// takes 103 us (the fused sweep's 91 us + 10 % per-tile work + launch); the state loads alone add 8 us, the stores alone
+// 9 us, both 22-25 us -- whether the next tile is prefetched (registers or LDS-DMA) or loaded when the tile is done, the
+// stores issued at the tile's end, deferred and spread over the next tile's draws, or paced two per Philox block; whether
+// the wavefronts of a workgroup start together or staggered; with any cache policy of the stores; from HBM or from a
+// 32 KiB region that never leaves the L2.  The SQ counters show the difference as issue stalls (SQ_WAIT_INST_ANY), not as
+// waits on memory; the shader clock stays at 2.33-2.40 GHz (1 360 W with the traffic, 1 000 W without).  The memory traffic
+// of the kernel on its own (-DME_DENSE64_F64_MEMORY_ONLY) takes 72 us.
 #pragma once
 
 #include "me_device.h"
 #include "me_per_device.h"
 
+#include <type_traits>
+
 namespace me {
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
-#ifndef ME_DENSE64_F64_PREFETCH_EARLY
-#define ME_DENSE64_F64_PREFETCH_EARLY 0
+#ifndef ME_DENSE64_F64_PREFETCH
+#define ME_DENSE64_F64_PREFETCH 2       // the next tile's rows: 0 = loaded when this tile is done, 1 = into a second register set, 2 = into LDS by the load unit
+#endif
+#ifndef ME_DENSE64_F64_STORE_AUX
+#define ME_DENSE64_F64_STORE_AUX 0      // cache policy of the state stores: bit 0 = sc0, bit 1 = nt, bit 4 = sc1
 #endif
 #ifndef ME_DENSE64_F64_STAGGER
-#define ME_DENSE64_F64_STAGGER 0
+#define ME_DENSE64_F64_STAGGER 0        // dev: wavefront w of a workgroup starts w x this many x 64 cycles late
 #endif
-#ifndef ME_DENSE64_F64_RNG_UNROLL
-#define ME_DENSE64_F64_RNG_UNROLL 2     // 2 blocks (4 Box-Muller pairs) per iteration: -2.5 % on the fused sweep against 1; 4: no further gain
+#ifndef ME_DENSE64_F64_EXPERIMENT
+#define ME_DENSE64_F64_EXPERIMENT 0     // dev: bit 0 = no state stores, bit 1 = no state loads, bit 3 = every tile uses the first 32 KiB of the state
 #endif
-#ifndef ME_DENSE64_F64_PRIO
-#define ME_DENSE64_F64_PRIO 0
-#endif
-#ifndef ME_DENSE64_F64_NT
-#define ME_DENSE64_F64_NT 0             // experiment: bit 0 = state loads non-temporal, bit 1 = state stores non-temporal
-#endif
+using f64x2 = __attribute__((ext_vector_type(2))) double;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 constexpr int kDense64F64Threads = 512;                  // 8 waves, two per SIMD
 constexpr int kDense64F64Frags = 40;                     // (mb, ks) pairs with 4 ks < 16 (mb + 1)
 constexpr int kDense64F64ImageDoubles = kDense64F64Frags * 64;
-constexpr int kDense64F64WaveDoubles = 64 * 32 + 128;    // xp[64 rows][32 chains] + the 2 x 4 x 16 energy exchange
+// per wavefront: the 2 x 4 x 16 energy exchange, 2 x 16 wall values, and the slab the next tile's rows are prefetched into
+constexpr int kDense64F64WaveDoubles = 160 + (ME_DENSE64_F64_PREFETCH == 2 ? 64 * 32 : 0);
 constexpr size_t kDense64F64LdsBytes = sizeof(double) * (kDense64F64ImageDoubles + 8 * kDense64F64WaveDoubles);
 
 __host__ __device__ constexpr int dense64_f64_frag_index(int mb, int ks) { return 2 * mb * (mb + 1) + ks; }
@@ -81,21 +91,63 @@ __global__ void k_dense64_f64_fragments(const double *__restrict__ m, double *__
   }
 }
 
-// ---- geometry: a wavefront owns a tile of 32 chains, each chain's 64 rows split over TWO lanes (lane = chain + 32 half,
-// half 0 owns rows 0..31, half 1 rows 32..63).  That halves the LDS a wavefront parks its proposals in (16 KiB) and the
-// registers a lane keeps state in (64 + 64 for the prefetched tile), so that TWO wavefronts fit each SIMD: while one is in
-// its arithmetic the other's rows travel.  (The first version gave a wavefront 64 chains: one wavefront per SIMD, and at
-// one sweep per launch the float64 pipe (~110 us) and HBM (~100 us) only overlapped through an explicit prefetch:
-// 160-170 us.)  Nothing else changes: a chain's draws, products and decisions are the same arithmetic in the same order.
+// ---- geometry.  A wavefront owns a tile of 32 chains and keeps state AND proposals in registers, in the matrix
+// instruction's own operand layout: lane (h, j) = (lane >> 4, lane & 15) owns rows {4 ks + h : ks < 16} of the two chains
+// 2 j and 2 j + 1 of the tile ("slots" ks, chain blocks nb = 0, 1).  That is at once
+//   * the B-operand layout of v_mfma_f64_16x16x4_f64 (k-step ks wants row 4 ks + h of column j from lane (h, j)): the
+//     proposals feed the matrix cores straight from the registers they were computed in;
+//   * its C/D layout (lane (h, j) receives rows 16 mb + h + 4 r of column j): row block mb of T x' (or of L g) arrives in the
+//     lanes that own those rows, as slots 4 mb + r -- the energy's partial dot products and the in-place L g need no
+//     data movement at all;
+//   * a memory access of 16 bytes per lane (both chains of a row are neighbours in the tile-major state): 16 loads and 16
+//     stores per tile, each covering four 256-byte row segments.
+// What does need to move are the normals: Philox block b of a chain yields the normals of rows 4 b .. 4 b + 3, one for
+// each of the chain's four lanes.  Lane h draws blocks 4 q + h (q < 4) of both chains and a 4 x 4 transposition across the
+// wavefront's four 16-lane rows (v_permlane32_swap + v_permlane16_swap, 8 instructions per four doubles) hands every
+// normal to its owner -- no lane draws anything twice.  The accept decision of chain nb is taken by the lanes with
+// h >> 1 == nb (twice each, as before); its four partial energies meet in 1 KiB of LDS.
+// The version before this one parked the proposals in LDS ([row][chain], 16 KiB per wavefront) between the draws, the
+// products and the decision: 240 LDS instructions per tile and sweep that are gone now, and the LDS they occupied takes
+// the NEXT tile's rows instead, written by the load unit itself (buffer_load ... lds) while this tile computes: no second
+// register set.
 constexpr int kTileChains64 = 32;
+constexpr int kDense64F64Slots = 16;                     // rows per lane and chain
 
-// swizzled position of (row, chain) in a wave's xp block [64 rows][32 chains]: odd rows swap the two 16-chain halves, so
-// that the two rows a 32-lane access group touches (lane >> 4 = 0, 1) fall into different halves of the 64 banks
-__device__ __forceinline__ int xp_at(int row, int chain) { return row * kTileChains64 + (chain ^ ((row & 1) << 4)); }
+// a[lanes 32-63] <-> b[lanes 0-31]
+__device__ __forceinline__ void swap_rows_by_32(double &a, double &b) {
+  const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+  // (the builtin's two results go through scalar locals: me_dense_mfma.h swap32)
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned int)ua, (unsigned int)ub, false, false);
+  const unsigned int lo0 = lo[0], lo1 = lo[1];
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned int)(ua >> 32), (unsigned int)(ub >> 32), false, false);
+  const unsigned int hi0 = hi[0], hi1 = hi[1];
+  a = __builtin_bit_cast(double, ((unsigned long long)hi0 << 32) | lo0);
+  b = __builtin_bit_cast(double, ((unsigned long long)hi1 << 32) | lo1);
+}
+// a[odd 16-lane rows] <-> b[even 16-lane rows]
+__device__ __forceinline__ void swap_rows_by_16(double &a, double &b) {
+  const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned int)ua, (unsigned int)ub, false, false);
+  const unsigned int lo0 = lo[0], lo1 = lo[1];
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned int)(ua >> 32), (unsigned int)(ub >> 32), false, false);
+  const unsigned int hi0 = hi[0], hi1 = hi[1];
+  a = __builtin_bit_cast(double, ((unsigned long long)hi0 << 32) | lo0);
+  b = __builtin_bit_cast(double, ((unsigned long long)hi1 << 32) | lo1);
+}
+// d[w] of 16-lane row h  <->  d[h] of row w
+__device__ __forceinline__ void transpose_rows_4x4(double (&d)[4]) {
+  swap_rows_by_32(d[0], d[2]);
+  swap_rows_by_32(d[1], d[3]);
+  swap_rows_by_16(d[0], d[1]);
+  swap_rows_by_16(d[2], d[3]);
+}
+// v as held by lanes 0-31 (`low`) and by lanes 32-63 (`high`), in every lane
+__device__ __forceinline__ void both_halves(double v, double &low, double &high) {
+  low = v;
+  high = v;
+  swap_rows_by_32(low, high);
+}
 
-// Y = T X for the wave's 32 columns parked in `xp`; row blocks ascending or descending; after each row block
-// `sink(mb, acc)` receives its two 16 x 16 result blocks (acc[nb][r]: row 16 mb + (lane >> 4) + 4 r of chain
-// 16 nb + (lane & 15)).  `frags`: the fragment image, in LDS (T) or global memory (the shared factor).
 // where the A-operand fragments come from: LDS (T, copied once per block) ...
 struct FragsInLds {
   const double *base;
@@ -114,9 +166,11 @@ struct FragsInGlobal {
   }
 };
 
+// Y = T X for the wave's 32 columns held in `v` (slot ks, chain block nb = v[ks][nb]); row blocks ascending or descending;
+// after each row block `sink(mb, acc)` receives its two 16 x 16 result blocks, acc[nb][r] = row 16 mb + h + 4 r = slot
+// 4 mb + r of this lane's chain of block nb.
 template <bool DESCENDING, class Frags, class Sink>
-__device__ __forceinline__ void wave_tri_product_64(const Frags &frags, const double *xp, int lane, Sink &&sink) {
-  const int j = lane & 15, h = lane >> 4;
+__device__ __forceinline__ void wave_tri_product_64(const Frags &frags, const f64x2 (&v)[kDense64F64Slots], int lane, Sink &&sink) {
 #pragma unroll
   for (int step = 0; step < 4; ++step) {
     const int mb = DESCENDING ? 3 - step : step;
@@ -127,14 +181,10 @@ __device__ __forceinline__ void wave_tri_product_64(const Frags &frags, const do
     for (int ks = 0; ks < 4 * (mb + 1); ++ks) {
       const double a = frags.get(dense64_f64_frag_index(mb, ks), lane);
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        const double b = xp[xp_at(4 * ks + h, 16 * nb + j)];
-        acc[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[nb], 0, 0, 0);
-      }
+      for (int nb = 0; nb < 2; ++nb) acc[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, v[ks][nb], acc[nb], 0, 0, 0);
     }
     sink(mb, acc);
-    // one row block at a time: without this fence hipcc merges the row blocks to share their B reads and keeps every
-    // accumulator live
+    // one row block at a time: without this fence hipcc merges the row blocks and keeps every accumulator live
     asm volatile("" ::: "memory");
   }
 }
@@ -142,14 +192,52 @@ __device__ __forceinline__ void wave_tri_product_64(const Frags &frags, const do
 template <int CK>
 __global__ void __launch_bounds__(kDense64F64Threads, 2)
     k_step_dense64_f64(StepArgs<double> a, const double *__restrict__ t_image, const double *__restrict__ l_image) {
-  constexpr int kRngUnroll = CK == CK_SHARED ? 1 : ME_DENSE64_F64_RNG_UNROLL;
-  constexpr int D = 64, H = 32;          // H rows per lane
+  constexpr int D = 64, S = kDense64F64Slots;
+  constexpr unsigned int kSlotBytes = 4u * TiledField<double>::kEntryBytes;      // slot ks -> row 4 ks + h: 2 KiB apart
   using N_ = Num<double>;
   extern __shared__ __attribute__((aligned(16))) double smem64[];
   double *lds_t = smem64;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double *xp = smem64 + kDense64F64ImageDoubles + wave * kDense64F64WaveDoubles;
-  double *exch = xp + D * kTileChains64;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  double *mine = smem64 + kDense64F64ImageDoubles + wave * kDense64F64WaveDoubles;
+  double *exch = mine;                       // [chain block][h][j]: the four partial energies of a chain
+  double *wall = mine + 128;                 // [chain block][j]: row 0 of the proposals, for the hard wall
+  [[maybe_unused]] double *slab = mine + 160;   // [slot][lane][chain block]: the next tile's rows
+  const int j = lane & 15, h = lane >> 4;
+  const int own = h >> 1;                    // the chain block whose accept decision, energy and width this lane carries
+  unsigned int wave_accepted = 0;
+  bool bad_energy = false, bad_width = false;
+  // the state is tile-major (me_device.h: XField), padded to whole 64-chain tiles and initialised there: a ragged last tile
+  // computes on the padding (energy and width of chains beyond n read as 0 through the range-checked descriptors, their
+  // stores are dropped)
+  const TiledField<double> fx(a.x, a.n, D);
+  const Field<double> fe(a.energy, a.n, 1), fw(a.width, a.n, 1);
+  const long long n_tiles = (a.n + kTileChains64 - 1) / kTileChains64;
+  const long long tile_stride = (long long)gridDim.x * (kDense64F64Threads / 64);
+  // byte offset of (row h, chain 2 j) of 32-chain tile t: t >> 1 is the 64-chain tile of the layout, t & 1 its half
+  auto state_off = [&](long long t) {
+    if constexpr ((ME_DENSE64_F64_EXPERIMENT & 8) != 0) t &= 1;      // dev: every tile reads and writes the first 32 KiB
+    return (unsigned int)(((t >> 1) * (long long)(D * 64) + (t & 1) * 32 + 2 * j) * 8) + (unsigned int)h * TiledField<double>::kEntryBytes;
+  };
+  auto load_rows = [&](long long t, f64x2 (&dst)[S]) {
+    const unsigned int off = state_off(t);
+#pragma unroll
+    for (int ks = 0; ks < S; ++ks) {
+      if constexpr ((ME_DENSE64_F64_EXPERIMENT & 2) != 0) dst[ks] = f64x2{(double)off, 0.0};
+      else dst[ks] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(fx.rsrc, off, (unsigned int)ks * kSlotBytes, 0));
+    }
+  };
+
+  long long tile = (long long)blockIdx.x * (kDense64F64Threads / 64) + wave;
+  f64x2 x[S];
+  double e = 0.0, w = 0.0;
+  if (tile < n_tiles) {
+    load_rows(tile, x);
+    const unsigned int coff = (unsigned int)(tile * kTileChains64 + 2 * j + own) * 8u;
+    e = fe.load(0, coff);
+    w = fw.load(0, coff);
+  }
+  // the workgroup's prologue runs BEHIND the first tile's loads (the loads of ~2 000 wavefronts go out at the same moment
+  // and take a few microseconds to come back)
   {   // the image in one batch of loads (a rolled copy loop waits for every load before it issues the next)
     constexpr int kPieces = kDense64F64ImageDoubles / kDense64F64Threads;
     static_assert(kPieces * kDense64F64Threads == kDense64F64ImageDoubles, "the image divides evenly over the workgroup");
@@ -160,178 +248,168 @@ __global__ void __launch_bounds__(kDense64F64Threads, 2)
     for (int k = 0; k < kPieces; ++k) lds_t[k * kDense64F64Threads + threadIdx.x] = piece[k];
   }
   N_::prepare();    // the log table of the float64 Box-Muller; ends with the block barrier that also covers lds_t
-
-  const int j = lane & 15, h = lane >> 4;                 // position in the MFMA result blocks
-  const int cl = lane & 31, half = lane >> 5;             // chain of the tile, and which 32 rows of it this lane owns
-  unsigned int wave_accepted = 0;
-  bool bad_energy = false, bad_width = false;
-  // the state is tile-major (me_device.h: XField): a wavefront's 32 chains x 64 rows are half of one contiguous 32 KiB block
-  const TiledField<double> fx(a.x, a.n, D);
-  const Field<double> fe(a.energy, a.n, 1), fw(a.width, a.n, 1);
-  const long long n_tiles = (a.n + kTileChains64 - 1) / kTileChains64;
-  const long long tile_stride = (long long)gridDim.x * (kDense64F64Threads / 64);
-
-  // every lane stays active (the MFMAs need the whole wavefront): tail lanes shadow the last chain
-  auto chain_of = [&](long long tile) {
-    const long long c_raw = tile * kTileChains64 + cl;
-    return c_raw < a.n ? c_raw : a.n - 1;
-  };
-  // lane offset into the state field: the chain's place in its tile, plus 32 rows for the upper half (the row index of
-  // load / store is a wave-uniform immediate)
-  auto state_off = [&](long long c) { return tiled_offset<double>(c, D) + (unsigned int)half * (unsigned int)H * TiledField<double>::kEntryBytes; };
-  long long tile = (long long)blockIdx.x * (kDense64F64Threads / 64) + wave;
-  double x[H], e = 0.0, w = 0.0;
-  if (tile < n_tiles) {
-    const long long c = chain_of(tile);
-    const unsigned int xoff = state_off(c);
-#pragma unroll
-    for (int i = 0; i < H; ++i) x[i] = (ME_DENSE64_F64_NT & 1) ? fx.load_nt(i, xoff) : fx.load(i, xoff);
-    e = fe.load(0, (unsigned int)c * 8u);
-    w = fw.load(0, (unsigned int)c * 8u);
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);        // enter the loop with nothing pending (see the end of the tile loop)
-#if ME_DENSE64_F64_PRIO
-  // the two wavefronts of a SIMD (wave, wave + 4) get different issue priorities: one runs ahead of the other instead of
-  // both finishing their tiles at the same moment
-  if (wave < 4) __builtin_amdgcn_s_setprio(2);
-#endif
-  if constexpr (ME_DENSE64_F64_STAGGER > 0) {
-    // the two wavefronts of a SIMD run the same program and start together: delay the second half of the workgroup so
-    // that one wavefront's memory phases fall into the other's arithmetic (guide: two waves per SIMD, item 9)
-    if (wave >= 4) {
+  __builtin_amdgcn_s_waitcnt(0x0F70);        // enter the loop with nothing pending
+#if ME_DENSE64_F64_STAGGER > 0
+  // every wavefront of the workgroup starts a little later than the one before it
 #pragma unroll 1
-      for (int k = 0; k < ME_DENSE64_F64_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
-    }
-  }
+  for (int k = 0; k < wave; ++k) __builtin_amdgcn_s_sleep(ME_DENSE64_F64_STAGGER);
+#endif
   while (tile < n_tiles) {
-    const long long c = chain_of(tile);
-    const bool live = tile * kTileChains64 + cl < a.n;
-    const unsigned int coff = (unsigned int)c * 8u;
-    const unsigned long long gid = a.chain_offset + (unsigned long long)c;
-    // the next tile's rows travel while this one computes (second register set)
+    const long long c_own = tile * kTileChains64 + 2 * j + own;
+    const bool live = c_own < a.n;
+    const unsigned int coff = (unsigned int)c_own * 8u;
+    const unsigned long long gid0 = a.chain_offset + (unsigned long long)(tile * kTileChains64 + 2 * j);
     const long long next = tile + tile_stride;
-    const bool have_next = next < n_tiles;
-    double xn[H], en = 0.0, wn = 0.0;
-    // (tile-major rows are compile-time immediates of the buffer instructions: nothing loop-invariant to keep in registers)
-    const TiledField<double> &fxt = fx;
+    const bool have_next = next < n_tiles;        // wave-uniform
+    double en = 0.0, wn = 0.0;
+#if ME_DENSE64_F64_PREFETCH == 1
+    f64x2 xn[S];
+#endif
+    // the next tile's rows travel while this one computes
     auto prefetch = [&]() {
-      if (have_next) {       // wave-uniform
-        const long long cn = chain_of(next);
-        const unsigned int noff = state_off(cn);
+      if (have_next) {
+        const unsigned int ncoff = (unsigned int)(next * kTileChains64 + 2 * j + own) * 8u;
+        en = fe.load(0, ncoff);
+        wn = fw.load(0, ncoff);
+#if ME_DENSE64_F64_PREFETCH == 1
+        load_rows(next, xn);
+#elif ME_DENSE64_F64_PREFETCH == 2
+        const unsigned int off = state_off(next);
 #pragma unroll
-        for (int i = 0; i < H; ++i) xn[i] = (ME_DENSE64_F64_NT & 1) ? fxt.load_nt(i, noff) : fxt.load(i, noff);
-        en = fe.load(0, (unsigned int)cn * 8u);
-        wn = fw.load(0, (unsigned int)cn * 8u);
+        for (int ks = 0; ks < S; ++ks)     // 64 lanes x 16 bytes land at slab[ks][lane]
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(fx.rsrc, (__attribute__((address_space(3))) void *)(slab + ks * 128), 16, off,
+                                                   (unsigned int)ks * kSlotBytes, 0, 0);
+#endif
       }
     };
-
-    if constexpr (ME_DENSE64_F64_PREFETCH_EARLY && CK != CK_SHARED) prefetch();
-#ifdef ME_DENSE64_F64_MEMORY_ONLY      // experiment: the kernel's memory traffic without its arithmetic
-    prefetch();
-    for (int s = 0; s < 0; ++s) {
-#else
-    for (int s = 0; s < a.n_sweeps; ++s) {
-#endif
+    if constexpr (CK != CK_SHARED) prefetch();
+    // one sweep; FIRST: the first of the tile, which carries the previous tile's stores (and, with a shared factor, the prefetch)
+    auto sweep = [&](auto first_tag, int s) {
+      constexpr bool FIRST = decltype(first_tag)::value;
       const unsigned long long step = a.step_index + (unsigned long long)s;
       // the fragment reads of T are loop-invariant (80 registers if hoisted out of the sweep loop): keep them here
       asm volatile("" ::: "memory");
-      // ---- this lane's 32 normals (Philox blocks 8 half .. 8 half + 7, two Box-Muller pairs each) -> LDS; a rolled loop
-#pragma unroll kRngUnroll
-      for (int k = 0; k < 8; ++k) {
-        const int b = 8 * half + k;
-        U4 ctr;
-        ctr.x = (uint32_t)gid;
-        ctr.y = (uint32_t)(gid >> 32);
-        ctr.z = (uint32_t)step;
-        ctr.w = ((uint32_t)(step >> 32) << 16) | (uint32_t)b;
-        const U4 o = philox4x32_10(ctr, a.seed_lo, a.seed_hi);
-        double g[4];
-        N_::normal_pair(o.x, o.y, g[0], g[1]);
-        N_::normal_pair(o.z, o.w, g[2], g[3]);
+      // ---- the normals: this lane draws Philox blocks 4 q + h of both chains (two Box-Muller pairs each); the
+      // transposition hands word w of block 4 q + h' to lane row w as slot 4 q + h'
+      f64x2 xp[S];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xp[xp_at(4 * b + i, cl)] = g[i];
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const unsigned long long gid = gid0 + (unsigned long long)nb;
+          U4 ctr;
+          ctr.x = (uint32_t)gid;
+          ctr.y = (uint32_t)(gid >> 32);
+          ctr.z = (uint32_t)step;
+          ctr.w = ((uint32_t)(step >> 32) << 16) | (uint32_t)(4 * q + h);
+          const U4 o = philox4x32_10(ctr, a.seed_lo, a.seed_hi);
+          double g[4];
+          N_::normal_pair(o.x, o.y, g[0], g[1]);
+          N_::normal_pair(o.z, o.w, g[2], g[3]);
+          transpose_rows_4x4(g);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) xp[4 * q + k][nb] = g[k];
+          __builtin_amdgcn_sched_barrier(0);      // one block at a time: interleaved, the blocks' temporaries spill the state
+        }
       }
-      __builtin_amdgcn_wave_barrier();
       if constexpr (CK == CK_SHARED) {
-        // y = L g, row blocks descending, written over g in place
+        // y = L g, row blocks descending: block mb overwrites slots 4 mb .. 4 mb + 3, which the later blocks do not read
         wave_tri_product_64<true>(FragsInGlobal(l_image), xp, lane, [&](int mb, const f64x4 (&acc)[2]) {
-          __builtin_amdgcn_wave_barrier();
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xp[xp_at(16 * mb + h + 4 * r, 16 * nb + j)] = acc[nb][r];
-          __builtin_amdgcn_wave_barrier();
+            for (int r = 0; r < 4; ++r) xp[4 * mb + r][nb] = acc[nb][r];
         });
+        // with a shared factor the prefetch stays behind the first sweep's L g, whose fragment loads from global memory
+        // would otherwise queue up behind it (loads return in order)
+        if constexpr (FIRST) prefetch();
       }
-      // The prefetch goes out here, behind the first sweep's draws: a wave can have at most 63 vector-memory operations
-      // outstanding (vmcnt is 6 bits), so queued directly behind the previous tile's stores it would stall the wave at
-      // issue; and with a shared factor it has to stay behind that sweep's L g, whose fragment loads from global memory
-      // would otherwise wait for it (loads return in order).
-      if (s == 0 && !(ME_DENSE64_F64_PREFETCH_EARLY && CK != CK_SHARED)) prefetch();
-      // x' = x + w g (or x + w L g) by the owners, in place
+      // x' = x + w g (or x + w L g)
+      double wv[2];
+      both_halves(w, wv[0], wv[1]);
 #pragma unroll
-      for (int i0 = 0; i0 < H; i0 += 8) {       // eight at a time: 32 reads in flight would be 64 more live registers
+      for (int ks = 0; ks < S; ++ks)
 #pragma unroll
-        for (int i = i0; i < i0 + 8; ++i) xp[xp_at(H * half + i, cl)] = x[i] + w * xp[xp_at(H * half + i, cl)];
-        asm volatile("" ::: "memory");
-      }
-      __builtin_amdgcn_wave_barrier();
-      // ---- E' = x'^T (T x'): partial dot products where the results are, then the exchange over the four row groups
+        for (int nb = 0; nb < 2; ++nb) xp[ks][nb] = __builtin_fma(wv[nb], xp[ks][nb], x[ks][nb]);
+      // ---- E' = x'^T (T x'): partial dot products where the results are, then the exchange over the four lane rows
       double part[2] = {0.0, 0.0};
       wave_tri_product_64<false>(FragsInLds{lds_t}, xp, lane, [&](int mb, const f64x4 (&acc)[2]) {
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) part[nb] = __builtin_fma(xp[xp_at(16 * mb + h + 4 * r, 16 * nb + j)], acc[nb][r], part[nb]);
+          for (int r = 0; r < 4; ++r) part[nb] = __builtin_fma(xp[4 * mb + r][nb], acc[nb][r], part[nb]);
       });
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) exch[(nb * 4 + h) * 16 + j] = part[nb];
+      const bool walled = a.reject_kind == ME_REJECT_ABS_REAL0_GE;      // wave-uniform
+      if (walled && h == 0) {
+        wall[j] = xp[0][0];
+        wall[16 + j] = xp[0][1];
+      }
       __builtin_amdgcn_wave_barrier();
-      double e_new = 0.0;      // both lanes of a chain sum the same four values in the same order
+      double e_new = 0.0;      // the four lanes of a chain block sum the same four values in the same order
 #pragma unroll
-      for (int hh = 0; hh < 4; ++hh) e_new += exch[((cl >> 4) * 4 + hh) * 16 + (cl & 15)];
+      for (int hh = 0; hh < 4; ++hh) e_new += exch[(own * 4 + hh) * 16 + j];
+      bool rejected = false;
+      if (walled) rejected = !(N_::abs_(wall[own * 16 + j]) < a.reject_bound);
       // ---- accept uniform: word 64 = block 16, output 0
+      const unsigned long long gid = gid0 + (unsigned long long)own;
       U4 ctr;
       ctr.x = (uint32_t)gid;
       ctr.y = (uint32_t)(gid >> 32);
       ctr.z = (uint32_t)step;
       ctr.w = ((uint32_t)(step >> 32) << 16) | 16u;
       const double u = N_::unit(philox4x32_10(ctr, a.seed_lo, a.seed_hi).x);
-      bool rejected = false;
-      if (a.reject_kind == ME_REJECT_ABS_REAL0_GE) rejected = !(N_::abs_(xp[xp_at(0, cl)]) < a.reject_bound);
       const double diff = e_new - e;
       bool accept = diff <= 0.0;
       if (a.temp > 0.0) accept = accept || N_::uphill(u, diff, a.inv_temp, a.inv_temp_log2e);
       accept = accept && !rejected;
       bad_energy |= (live && !rejected && !N_::finite(e_new));
-      if (accept) {
+      // lanes 0-15 speak for chain block 0, lanes 32-47 for chain block 1
+      const unsigned long long votes = __ballot(accept);
+      const bool take0 = (((unsigned int)votes >> j) & 1u) != 0u, take1 = (((unsigned int)(votes >> 32) >> j) & 1u) != 0u;
 #pragma unroll
-        for (int i = 0; i < H; ++i) x[i] = xp[xp_at(H * half + i, cl)];
+      for (int ks = 0; ks < S; ++ks) {
+        x[ks][0] = take0 ? xp[ks][0] : x[ks][0];
+        x[ks][1] = take1 ? xp[ks][1] : x[ks][1];
       }
       e = accept ? e_new : e;
       w = N_::adapt(w, accept, a.ratio, a.p, a.damping, a.up, a.down);
-      wave_accepted += (unsigned int)__popcll(__ballot(accept && live && half == 0));
-      __builtin_amdgcn_wave_barrier();      // the next sweep overwrites xp
-    }
+      wave_accepted += (unsigned int)__popcll(__ballot(accept && live && (h & 1) == 0));
+      __builtin_amdgcn_wave_barrier();      // the next sweep overwrites the exchange
+    };
+#ifndef ME_DENSE64_F64_MEMORY_ONLY     // (defined: the kernel's memory traffic without its arithmetic)
+    sweep(std::true_type{}, 0);
+    for (int s = 1; s < a.n_sweeps; ++s) sweep(std::false_type{}, s);
+#endif
     bad_width |= live && !(w > 0.0);
-    // vmcnt is a 6-bit counter and memory operations retire in order: once this tile's stores and the next prefetch's
-    // loads are queued behind them, ANY wait on the rows prefetched above can only be expressed as "drain (almost)
-    // everything".  Wait for them here instead -- they were issued most of a tile of arithmetic ago.
+    // The prefetch was issued a tile of arithmetic ago: wait for it BEFORE this tile's stores are queued behind it (vmcnt
+    // counts in order; afterwards any wait on the prefetch would drain the stores as well).
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
-    if (live) {
-      const unsigned int xoff = state_off(c);
+    {
+      const unsigned int off = state_off(tile);
 #pragma unroll
-      for (int i = 0; i < H; ++i) {
-        if constexpr ((ME_DENSE64_F64_NT & 2) != 0) fxt.store_nt(i, xoff, x[i]);
-        else fxt.store(i, xoff, x[i]);
-      }
-      if (half == 0) {
+      for (int ks = 0; ks < S; ++ks)
+        if ((ME_DENSE64_F64_EXPERIMENT & 1) == 0 || x[ks][0] == 1.2345)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x[ks]), fx.rsrc, off, (unsigned int)ks * kSlotBytes, ME_DENSE64_F64_STORE_AUX);
+      if (live && (h & 1) == 0) {
         fe.store(0, coff, e);
         fw.store(0, coff, w);
       }
     }
+    if (have_next) {
+#if ME_DENSE64_F64_PREFETCH == 1
 #pragma unroll
-    for (int i = 0; i < H; ++i) x[i] = xn[i];
+      for (int ks = 0; ks < S; ++ks) x[ks] = xn[ks];
+#elif ME_DENSE64_F64_PREFETCH == 2
+#pragma unroll
+      for (int ks = 0; ks < S; ++ks) x[ks] = *reinterpret_cast<const f64x2 *>(slab + ks * 128 + lane * 2);
+      __builtin_amdgcn_s_waitcnt(0xC07F);    // lgkmcnt(0): the slab is free for the next prefetch
+#else
+      load_rows(next, x);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+    }
     e = en;
     w = wn;
     tile = next;
