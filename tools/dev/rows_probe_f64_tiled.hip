@@ -20,6 +20,29 @@ __global__ void __launch_bounds__(64) k(double *rw, double *ew, long long n) {
 #pragma unroll
   for (int r = 0; r < RW; ++r) *at(r) = x[r] * 1.0000001 + 1e-30;
 }
+// 16-byte accesses: [tile of 64][row pair][64 lanes][2]: two rows of one chain are neighbours, 9 loads + 9 stores per lane
+__global__ void __launch_bounds__(64) k_pairs(double2 *rw, long long n) {
+  const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (c >= n) return;
+  double2 *p = rw + (c >> 6) * 9 * 64 + (c & 63);
+  double2 x[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) x[r] = p[r * 64];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) p[r * 64] = double2{x[r].x * 1.0000001 + 1e-30, x[r].y * 1.0000001 + 1e-30};
+}
+// ... and four rows of one chain as two 16-byte halves 1 KiB apart is what a b128 access of [tile][row quad][64][4] would be;
+// the same bytes per instruction as k_pairs, half as many 512-byte row segments: not tried (18 rows do not divide by 4)
+void run_pairs(int lg, double *rw) {
+  const long long n = 1ll << lg;
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k_pairs, dim3((unsigned)(n / 64)), dim3(64), 0, 0, (double2 *)rw, n);
+  (void)hipEventRecord(e0);
+  for (int i = 0; i < 100; ++i) hipLaunchKernelGGL(k_pairs, dim3((unsigned)(n / 64)), dim3(64), 0, 0, (double2 *)rw, n);
+  (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  printf("%-44s 2^%d chains: %7.1f us  %5.0f GB/s\n", "tile-major row PAIRS, 16-byte accesses", lg, ms * 10, 288.0 * n / (ms * 10) / 1e3);
+}
 template <int MODE>
 void run(const char *name, int lg, double *rw, double *ew) {
   const long long n = 1ll << lg;
@@ -40,6 +63,7 @@ int main() {
       run<0>("component-major", lg, rw, ew);
       run<1>("tile-major (x, energy, width in one block)", lg, rw, ew);
       run<2>("x tile-major, energy / width separate", lg, rw, ew);
+      run_pairs(lg, rw);
     }
     (void)hipFree(rw); (void)hipFree(ew);
   }
