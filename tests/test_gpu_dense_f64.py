@@ -96,6 +96,29 @@ def test_dense64_f64_full_size_shard_equivalence_and_moments():
     assert 0.15 < st["acceptance_rate"] < 0.5
 
 
+@pytest.mark.parametrize("n", [1, 31, 33, 95])
+def test_dense64_f64_ragged_tiles_are_shards_of_a_larger_engine(n):
+    """Chain counts that leave a wavefront's 32-chain tile (two chains per lane) partly or almost wholly empty: the n chains
+    are bit for bit the first n of a 128-chain engine, with the identity shape and with a shared factor."""
+    kw = dict(temp=1.0, seed=77, sampling_width=0.15, dtype="f64")
+    x0 = list(np.linspace(-0.2, 0.4, 64))
+    factor = _packed_lower(np.linalg.cholesky(0.5 * np.linalg.inv(AMAT)))
+    for mode in ("fixed", "pooled"):
+        big = me.MetropolisEngine(me.DenseQuadratic(AMAT), None, x0, None, n_chains=128, cov_mode=mode, **kw)
+        small = me.MetropolisEngine(me.DenseQuadratic(AMAT), None, x0, None, n_chains=n, cov_mode=mode, **kw)
+        if mode == "pooled":
+            big.set_shared_factor(factor)
+            small.set_shared_factor(factor)
+        for fused in (1, 3, 1):
+            big.step_all(fused)
+            small.step_all(fused)
+        assert np.array_equal(big._get(0)[:n], small._get(0))
+        # (a one-chain engine reports scalars, as the reference does)
+        assert np.array_equal(big.energy_total[:n], np.atleast_1d(small.energy_total))
+        assert np.array_equal(big.real_group_sampling_width[:n], np.atleast_1d(small.real_group_sampling_width))
+        assert small.accept_stats()[1] == 5 * n
+
+
 def test_pooled_moments_float64_gram_kernel_matches_numpy():
     """64 real parameters in float64 pool their second moments with v_mfma_f64_16x16x4_f64 (me_pool_gram.h,
     k_pool_gram64_f64): the result is the plain float64 sums over the chains' current states -- ragged last tile, several
