@@ -9,6 +9,7 @@
 #include <mutex>
 #include <string>
 #include <atomic>
+#include <chrono>
 #include <vector>
 
 #include "me_comm.h"
@@ -1305,12 +1306,25 @@ int me_comm_info(me_engine *e, int32_t *rank, int32_t *world, int32_t *rccl_vers
   return ME_OK;
 }
 
+// Waits for `ev`, polling for the first two milliseconds.  hipEventSynchronize gives up its own active wait after a few
+// microseconds and blocks; the thread is then woken by an interrupt, and on a host that is otherwise idle (one OpenMP
+// thread, as torch.distributed.run sets it) the core has gone to sleep by then: the overlapped config 5 loop, whose host side
+// is 85 us per cycle, ran 3-5 x slower there.
+static hipError_t wait_polling(hipEvent_t ev) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t rc = hipEventQuery(ev);
+    if (rc != hipErrorNotReady) return rc;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipEventSynchronize(ev);
+  }
+}
+
 int me_pooled_moments_end(me_engine *e, double *host_out, int64_t n_doubles) {
   if (!e || !host_out) return ME_ERR_INVALID;
   if (!e->pool_pending) return fail(e, ME_ERR_STATE, "no pooled-moment reduction in flight: call me_pooled_moments_begin first");
   if (n_doubles != moments_size(e->nr, e->nc)) return fail(e, ME_ERR_INVALID, "wrong pooled-moment buffer length");
   ME_HIP(e, hipSetDevice(e->device));
-  ME_HIP(e, hipEventSynchronize(e->pool_copied));
+  ME_HIP(e, wait_polling(e->pool_copied));
   e->pool_pending = false;
   std::memcpy(host_out, e->pool_host, sizeof(double) * (size_t)n_doubles);
   return ME_OK;
