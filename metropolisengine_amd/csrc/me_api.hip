@@ -442,11 +442,11 @@ int me_create(const me_config *c, me_engine **out) {
     return fail(nullptr, ME_ERR_UNSUPPORTED,
                 "ME_REJECT_USER: this user-energy plugin defines no me_user_reject (#define ME_USER_HAS_REJECT in its source)");
   if (ks->n_real < 0) {   // the runtime-dimension kernel set (me_runtime_dims.hip)
-    if (c->cov_mode == ME_COV_REFERENCE || (c->cov_mode == ME_COV_POOLED && c->n_complex > 0))
+    if ((c->cov_mode == ME_COV_REFERENCE || c->cov_mode == ME_COV_POOLED) && c->n_complex > 0)
       return fail(nullptr, ME_ERR_UNSUPPORTED,
-                  "parameter spaces beyond " + std::to_string(kMaxRegisterDof) + " real degrees of freedom run with the "
-                  "identity proposal shape (ME_COV_FIXED, cov_mode=\"fixed\") or, pure real spaces, one shared factor "
-                  "(ME_COV_POOLED); per-chain shapes are not available there");
+                  "parameter spaces beyond " + std::to_string(kMaxRegisterDof) + " real degrees of freedom with complex "
+                  "parameters run with the identity proposal shape (ME_COV_FIXED, cov_mode=\"fixed\"); per-chain shapes "
+                  "(ME_COV_REFERENCE) and one shared factor (ME_COV_POOLED) are there for pure real spaces");
     // an initial covariance that is not the identity makes the engine start with a SHARED factor (cov_kind below), which the
     // runtime set has for pure real spaces only and which doubles the LDS a block needs
     const bool starts_shared = !initial_shape_is_identity(c);
@@ -458,11 +458,13 @@ int me_create(const me_config *c, me_engine **out) {
       // a dense energy needs all of x' at once, a shared factor all of g: both are parked in LDS, 64 lanes x D values each
       const long long per_block = (long long)(c->n_real + 2 * c->n_complex) * 64 * (c->dtype == ME_F32 ? 4 : 8);
       const bool dense = c->energy_kind == ME_ENERGY_DENSE_QUAD, pooled = c->cov_mode == ME_COV_POOLED || starts_shared;
-      if ((dense || pooled) && per_block * (pooled ? 2 : 1) > 150 * 1024)
+      // per-chain shapes (and the tracking flag): x' / the deviations from the running mean / a row of the factor, D values per lane
+      const bool per_chain = c->cov_mode == ME_COV_REFERENCE || (c->flags & ME_FLAG_TRACK_COVARIANCE) != 0;
+      if ((dense || pooled || per_chain) && per_block * (pooled ? 2 : 1) > 150 * 1024)
         return fail(nullptr, ME_ERR_UNSUPPORTED,
-                    "a dense quadratic form or a shared proposal factor beyond " + std::to_string(kMaxRegisterDof) +
-                        " degrees of freedom is staged in LDS: this many parameters do not fit (float64: about 290 with the "
-                        "identity shape, 145 with a shared factor; float32 twice that)");
+                    "a dense quadratic form, a shared proposal factor or per-chain shapes beyond " + std::to_string(kMaxRegisterDof) +
+                        " degrees of freedom are staged in LDS: this many parameters do not fit (float64: about 290, 145 with "
+                        "a shared factor or an initial covariance; float32 twice that)");
     }
     if (c->flags & ME_FLAG_REFERENCE_ENERGY_LEDGERS)
       return fail(nullptr, ME_ERR_UNSUPPORTED, "ME_FLAG_REFERENCE_ENERGY_LEDGERS is not available beyond " +

@@ -20,8 +20,16 @@
 //                    Limits: the LDS a block may use (D <= ~290 in float64 with the identity shape, ~145 with a shared
 //                    factor; twice that in float32).
 //
+//   per-chain proposal shapes (ME_COV_REFERENCE, pure real spaces: the reference's semantics, :416-421 feeding :261-272):
+//                    k_measure_runtime_cov keeps each chain's running covariance (packed, tile-major, streamed),
+//                    k_factor_runtime refreshes its Cholesky factor row by row, and k_step_runtime_lds<CK_PER_CHAIN> forms
+//                    x' = x + sigma L_chain g by columns, four at a time, with only x' parked in LDS.  Written for
+//                    completeness at any size the LDS admits (float64: 290 parameters), not for speed: a step reads the
+//                    chain's whole factor (D(D+1)/2 values), a refresh is D^3/6 dependent multiply-adds per lane.
+//
 // Supported: ME_ENERGY_ISO_QUAD, ME_ENERGY_DIAG_QUAD (streamed), ME_ENERGY_DENSE_QUAD (LDS); the identity proposal
-// shape (ME_COV_FIXED) and, for pure real spaces, one shared factor (ME_COV_POOLED); the built-in wall, step_all and
+// shape (ME_COV_FIXED) and, for pure real spaces, one shared factor (ME_COV_POOLED) or per-chain shapes
+// (ME_COV_REFERENCE); running per-chain covariances for statistics (ME_FLAG_TRACK_COVARIANCE); the built-in wall, step_all and
 // group-wise steps of mixed engines.  The word layout of a step is the one of every
 // other kernel (oracle/philox.py): normal i belongs to coordinate i, word 2 ceil(D/2) is the accept uniform.
 #include <type_traits>
@@ -177,6 +185,163 @@ __global__ void __launch_bounds__(kBlockThreads) k_measure_runtime(MeasureArgs<R
       a.obs_mean[i] = a.obs_mean[i] * a.keep + o * a.inv_i;
     }
   }
+}
+
+// measure() of an engine that keeps per-chain covariance matrices at runtime dimensions (cov_mode="reference" on pure real
+// spaces, or the tracking flag): means and observables as above, then the covariance recursion of k_measure's streaming
+// path (me_device.h: delta = x - mu_old parked in LDS, the packed entries of the tile-major field walked in their own
+// order, batches of loads ahead of their updates; :416-427 in the one-pass form).  One wavefront per block, one lane per
+// chain, dynamic LDS delta[D][64].
+template <typename R>
+__global__ void __launch_bounds__(kStepThreads) k_measure_runtime_cov(MeasureArgs<R> a, int nr, int nc) {
+  using N_ = Num<R>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_rt[];
+  R(*delta)[kStepThreads] = reinterpret_cast<R(*)[kStepThreads]>(smem_rt);
+  const int D = nr + 2 * nc, nobs = 2 * nr + nc, lane = threadIdx.x;
+  const long long P = (long long)nr * (nr + 1) / 2 + (long long)nc * nc;
+  const bool mixed = nr > 0 && nc > 0;
+  const long long stride = (long long)gridDim.x * kStepThreads, n = a.n;
+  for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < n; c += stride) {
+    for (int d = 0; d < D; ++d) {                                                          // :404-410
+      const long long i = (long long)d * n + c;
+      const R mu = a.mean[i], xd = a.x[i];
+      delta[d][lane] = xd - mu;
+      a.mean[i] = mu * a.keep + xd * a.inv_i;
+    }
+    for (int k = 0; k < nobs; ++k) {                                                       // :458-463, :412-414
+      R o;
+      if (k < nr) o = N_::abs_(a.x[(long long)k * n + c]);
+      else if (k < nr + nc) {
+        const R re = a.x[(long long)k * n + c], im = a.x[(long long)(k + nc) * n + c];
+        o = N_::sqrt_(re * re + im * im);
+      } else {
+        const R v = a.x[(long long)(k - nr - nc) * n + c];
+        o = v * v;
+      }
+      const long long i = (long long)k * n + c;
+      a.obs_mean[i] = a.obs_mean[i] * a.keep + o * a.inv_i;
+    }
+    if (!a.update_cov) continue;
+    // :418, :425 -- each block uses its own group's width; they coincide unless group steps made them differ
+    R w_real = a.width[c], w_cplx = w_real;
+    if (mixed && a.split_widths) {
+      w_real = a.width[(long long)GROUP_REAL * n + c];
+      w_cplx = a.width[(long long)GROUP_COMPLEX * n + c];
+    }
+    const R w2_real = w_real * w_real, w2_cplx = w_cplx * w_cplx;
+    R *q = a.cov + (c >> 6) * P * 64 + (c & 63);
+    constexpr long long ts = 64;
+    for (int i = 0; i < nr; ++i) {
+      const R di = delta[i][lane];
+      int j = 0;
+      for (; j + 16 <= i; j += 16) {       // all loads first: a store to q[.] would fence the next load
+        R v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = q[u * ts];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) q[u * ts] = fma_(di * delta[j + u][lane], a.inv_i, v[u] * a.cov_keep);
+        q += 16 * ts;
+      }
+      for (; j < i; ++j) {
+        *q = fma_(di * delta[j][lane], a.inv_i, *q * a.cov_keep);
+        q += ts;
+      }
+      *q = fma_(w2_real, a.inv_i, fma_(di * di, a.inv_i, *q * a.cov_keep));
+      q += ts;
+    }
+    for (int i = 0; i < nc; ++i) {         // the Hermitian block: (Re, Im) of the columns j < i, then the real diagonal
+      const R ai = delta[nr + i][lane], bi = delta[nr + nc + i][lane];
+      for (int j = 0; j < i; ++j) {
+        const R aj = delta[nr + j][lane], bj = delta[nr + nc + j][lane];
+        const R re = q[0], im = q[ts];
+        q[0] = fma_(fma_(ai, aj, bi * bj), a.inv_i, re * a.cov_keep);
+        q[ts] = fma_(fma_(bi, aj, -(ai * bj)), a.inv_i, im * a.cov_keep);
+        q += 2 * ts;
+      }
+      *q = fma_(w2_cplx, a.inv_i, fma_(fma_(ai, ai, bi * bi), a.inv_i, *q * a.cov_keep));
+      q += ts;
+    }
+  }
+}
+
+// factor = chol(C) per chain at runtime dimensions (pure real spaces): k_factor_stream of me_device.h with the row block in
+// dynamic LDS (rows[ROWS][nr][64]) -- Cholesky-Banachiewicz, each lane its own chain, finished rows re-read from the
+// factor field itself, ROWS rows built together so that every finished L_jk that is loaded serves ROWS dot products.
+template <typename R, int ROWS>
+__global__ void __launch_bounds__(kStepThreads) k_factor_runtime(const R *cov, R *factor, unsigned int *status, long long n, int nr) {
+  using N_ = Num<R>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_rt[];
+  R(*lds)[kStepThreads] = reinterpret_cast<R(*)[kStepThreads]>(smem_rt);
+  auto row_of = [&](int r) { return lds + (size_t)r * nr; };          // rows[r][k][lane] = row_of(r)[k][lane]
+  const long long P = (long long)nr * (nr + 1) / 2;
+  bool bad_pivot = false;
+  const long long stride = (long long)gridDim.x * kStepThreads;
+  const int lane = threadIdx.x;
+  for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < n; c += stride) {
+    const long long base = (c >> 6) * P * 64 + (c & 63);
+    const R *cv = cov + base;
+    R *fc = factor + base;
+    for (int i0 = 0; i0 < nr; i0 += ROWS) {
+      const int nrows = nr - i0 < ROWS ? nr - i0 : ROWS;
+      for (int r = 0; r < nrows; ++r) {                    // the covariance rows of the block into LDS
+        const R *src = cv + (long long)tri(i0 + r, 0) * 64;
+        int j = 0;
+        for (; j + 16 <= i0 + r + 1; j += 16) {
+          R v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = src[(j + u) * 64];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) row_of(r)[j + u][lane] = v[u];
+        }
+        for (; j <= i0 + r; ++j) row_of(r)[j][lane] = src[j * 64];
+      }
+      for (int j = 0; j < i0; ++j) {                       // columns left of the block: row j serves all rows of the block
+        const R *lj = fc + (long long)tri(j, 0) * 64;
+        R sum[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) sum[r] = R(0);
+        int k = 0;
+        for (; k + 16 <= j; k += 16) {
+          R f[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) f[u] = lj[(k + u) * 64];
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+              if (r < nrows) sum[r] += row_of(r)[k + u][lane] * f[u];
+        }
+        for (; k < j; ++k) {
+          const R f = lj[k * 64];
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r)
+            if (r < nrows) sum[r] += row_of(r)[k][lane] * f;
+        }
+        const R inv = R(1) / lj[j * 64];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+          if (r < nrows) row_of(r)[j][lane] = (row_of(r)[j][lane] - sum[r]) * inv;
+      }
+      for (int r = 0; r < nrows; ++r) {                    // the triangle inside the block: everything is in LDS
+        const int i = i0 + r;
+        for (int j = i0; j < i; ++j) {
+          const int rj = j - i0;
+          R t = R(0);
+          for (int k = 0; k < j; ++k) t += row_of(r)[k][lane] * row_of(rj)[k][lane];
+          row_of(r)[j][lane] = (row_of(r)[j][lane] - t) / row_of(rj)[j][lane];
+        }
+        R t = row_of(r)[i][lane];
+        for (int k = 0; k < i; ++k) t -= row_of(r)[k][lane] * row_of(r)[k][lane];
+        if (!(t > R(0))) { bad_pivot = true; t = R(1e-30); }
+        row_of(r)[i][lane] = N_::sqrt_(t);
+      }
+      for (int r = 0; r < nrows; ++r) {                    // finished rows out (re-read by this same lane: program order suffices)
+        R *dst = fc + (long long)tri(i0 + r, 0) * 64;
+        for (int j = 0; j <= i0 + r; ++j) dst[j * 64] = row_of(r)[j][lane];
+      }
+    }
+  }
+  if (bad_pivot) atomicOr(status, (unsigned int)ST_BAD_PIVOT);
 }
 
 template <typename R>
@@ -345,8 +510,9 @@ __device__ __forceinline__ void lds_handover() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <typename R, bool SHARED>
+template <typename R, int CK>
 __global__ void __launch_bounds__(kStepThreads) k_step_runtime_lds(StepArgs<R> a, RuntimeStep<R> p, const R *__restrict__ folded) {
+  constexpr bool SHARED = CK == CK_SHARED;
   using N_ = Num<R>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_rt[];
   const int nr = p.nr, nc = p.nc, D = nr + 2 * nc;
@@ -397,7 +563,8 @@ __global__ void __launch_bounds__(kStepThreads) k_step_runtime_lds(StepArgs<R> a
         for (int t = 0; t < kStateBatch; ++t)
           if (d0b + t < D) xp[d0b + t][lane] = xd[t];
       }
-      // ---- the normals: straight into x' (identity shape) or parked (shared factor)
+      // ---- the normals: straight into x' (identity shape), parked (shared factor), or spread over x' through the
+      // chain's own factor
       for (int b = 0; 4 * b < NW; ++b) {
         const U4 o = block_of(b);
         R g[4];
@@ -408,7 +575,50 @@ __global__ void __launch_bounds__(kStepThreads) k_step_runtime_lds(StepArgs<R> a
           const int d = 4 * b + t;
           if (d < D) {
             if constexpr (SHARED) gs[d][lane] = g[t];
-            else if (d >= d0 && d < d1) xp[d][lane] = fma_(d < nr ? s_r : s_c, g[t], xp[d][lane]);
+            else if constexpr (CK == CK_PER_CHAIN) {
+              // (below, a whole Philox block at a time)
+            } else if (d >= d0 && d < d1) xp[d][lane] = fma_(d < nr ? s_r : s_c, g[t], xp[d][lane]);
+          }
+        }
+        if constexpr (CK == CK_PER_CHAIN) {
+          // x' = x + w L g by COLUMNS (pure real spaces), four at a time: the normals of this Philox block add
+          // w (g_0 L_i,4b + ... + g_3 L_i,4b+3) to every row i >= 4 b.  Only x' has to be parked that way (row by row, all of g
+          // would be needed as well); the four entries of a row are neighbours in the packed order, i.e. 4 x 64 values of the
+          // wavefront's chains in one 2 KiB run of the tile-major factor field; sixteen loads (four rows) are issued together.
+          const int db = 4 * b;
+          R sg[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) sg[t] = db + t < D ? s_r * g[t] : R(0);
+          const R *fac = a.factor + (c >> 6) * ((long long)D * (D + 1) / 2) * 64 + (c & 63);
+          for (int i = db; i < db + 4 && i < D; ++i) {        // the triangle on the diagonal: row i has columns 4 b .. i
+            const R *row = fac + (long long)tri(i, db) * 64;
+            R acc = xp[i][lane];
+            for (int t = 0; t <= i - db; ++t) acc = fma_(sg[t], row[t * 64], acc);
+            xp[i][lane] = acc;
+          }
+          int i = db + 4;
+          for (; i + 4 <= D; i += 4) {
+            R f[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const R *row = fac + (long long)tri(i + u, db) * 64;
+#pragma unroll
+              for (int t = 0; t < 4; ++t) f[u][t] = row[t * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              R acc = xp[i + u][lane];
+#pragma unroll
+              for (int t = 0; t < 4; ++t) acc = fma_(sg[t], f[u][t], acc);
+              xp[i + u][lane] = acc;
+            }
+          }
+          for (; i < D; ++i) {
+            const R *row = fac + (long long)tri(i, db) * 64;
+            R acc = xp[i][lane];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = fma_(sg[t], row[t * 64], acc);
+            xp[i][lane] = acc;
           }
         }
       }
@@ -537,7 +747,7 @@ int grid_of(long long n, int requested) {
 template <typename R>
 hipError_t step(const StepLaunch &l, hipStream_t stream) {
   if (l.inj_normals) return hipErrorNotSupported;
-  if (l.cov_kind != CK_IDENTITY && !(l.cov_kind == CK_SHARED && l.n_complex == 0)) return hipErrorNotSupported;
+  if (l.cov_kind != CK_IDENTITY && !((l.cov_kind == CK_SHARED || l.cov_kind == CK_PER_CHAIN) && l.n_complex == 0)) return hipErrorNotSupported;
   const bool mixed = l.n_real > 0 && l.n_complex > 0;
   if (l.group != GROUP_ALL && !mixed) return hipErrorInvalidValue;
   RuntimeStep<R> p;
@@ -565,26 +775,30 @@ hipError_t step(const StepLaunch &l, hipStream_t stream) {
   a.damping = (R)l.damping;
   a.up = (R)(l.ratio * (1.0 - l.target_acceptance) / l.damping);
   a.down = (R)(-l.ratio * l.target_acceptance / l.damping);
-  if (l.energy_kind == ME_ENERGY_DENSE_QUAD || l.cov_kind == CK_SHARED) {
-    // the LDS form: one wavefront per block, x' (and g) parked per lane
+  if (l.energy_kind == ME_ENERGY_DENSE_QUAD || l.cov_kind != CK_IDENTITY) {
+    // the LDS form: one wavefront per block, x' (and, with a shared factor, g) parked per lane
     const bool shared = l.cov_kind == CK_SHARED;
     const size_t lds = (size_t)(l.n_real + 2 * l.n_complex) * kStepThreads * sizeof(R) * (shared ? 2 : 1);
     if (lds > kRuntimeLdsLimit) return hipErrorNotSupported;
     a.factor = (const R *)l.factor;
     long long blocks = (l.n + kStepThreads - 1) / kStepThreads;
     if (l.grid_blocks > 0 && blocks > l.grid_blocks) blocks = l.grid_blocks;
-    static PerDevice<hipError_t> attr_cache[2];
+    const R *folded = l.energy_kind == ME_ENERGY_DENSE_QUAD ? (const R *)l.coef_device : nullptr;
     int device = 0;
     if (hipError_t rc = hipGetDevice(&device); rc != hipSuccess) return rc;
-    const hipError_t rc = attr_cache[shared ? 1 : 0].get(device, [shared] {
-      return shared ? hipFuncSetAttribute((const void *)k_step_runtime_lds<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRuntimeLdsLimit)
-                    : hipFuncSetAttribute((const void *)k_step_runtime_lds<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRuntimeLdsLimit);
-    });
-    if (rc != hipSuccess) return rc;
-    const R *folded = l.energy_kind == ME_ENERGY_DENSE_QUAD ? (const R *)l.coef_device : nullptr;
-    if (shared) hipLaunchKernelGGL((k_step_runtime_lds<R, true>), dim3((unsigned)blocks), dim3(kStepThreads), lds, stream, a, p, folded);
-    else hipLaunchKernelGGL((k_step_runtime_lds<R, false>), dim3((unsigned)blocks), dim3(kStepThreads), lds, stream, a, p, folded);
-    return hipGetLastError();
+    auto launch = [&](auto ck) -> hipError_t {
+      constexpr int CK = decltype(ck)::value;
+      static PerDevice<hipError_t> attr_cache;
+      const hipError_t rc = attr_cache.get(device, [] {
+        return hipFuncSetAttribute((const void *)k_step_runtime_lds<R, CK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRuntimeLdsLimit);
+      });
+      if (rc != hipSuccess) return rc;
+      hipLaunchKernelGGL((k_step_runtime_lds<R, CK>), dim3((unsigned)blocks), dim3(kStepThreads), lds, stream, a, p, folded);
+      return hipGetLastError();
+    };
+    if (shared) return launch(std::integral_constant<int, CK_SHARED>{});
+    if (l.cov_kind == CK_PER_CHAIN) return launch(std::integral_constant<int, CK_PER_CHAIN>{});
+    return launch(std::integral_constant<int, CK_IDENTITY>{});
   }
   // the acceptance slots are sized for 64-thread blocks over all chains; a 256-thread grid uses a quarter of them
   hipLaunchKernelGGL(k_step_runtime<R>, dim3(grid_of(l.n, l.grid_blocks)), dim3(kBlockThreads), 0, stream, a, p);
@@ -595,14 +809,55 @@ template <typename R>
 hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
   MeasureArgs<R> a{};
   a.x = (const R *)l.x;
+  a.width = (const R *)l.width;
   a.mean = (R *)l.mean;
+  a.cov = (R *)l.cov;
   a.obs_mean = (R *)l.obs_mean;
+  a.factor = (R *)l.factor;
+  a.status = l.status;
   a.n = l.n;
   const double i = (double)l.measure_count;
   a.keep = (R)((i - 1.0) / i);
   a.inv_i = (R)(1.0 / i);
-  hipLaunchKernelGGL(k_measure_runtime<R>, dim3(grid_of(l.n, l.grid_blocks)), dim3(kBlockThreads), 0, stream, a, l.n_real,
-                     l.n_complex);
+  a.cov_keep = (R)((i - 2.0) / (i - 1.0));
+  a.update_cov = l.update_cov;
+  a.split_widths = l.split_widths;
+  a.write_factor = l.write_factor;
+  if (!l.cov) {
+    hipLaunchKernelGGL(k_measure_runtime<R>, dim3(grid_of(l.n, l.grid_blocks)), dim3(kBlockThreads), 0, stream, a, l.n_real,
+                       l.n_complex);
+    return hipGetLastError();
+  }
+  // engines that keep per-chain covariance matrices: one wavefront per block, delta (and the factor kernel's row block) in LDS
+  const size_t row_bytes = (size_t)(l.n_real + 2 * l.n_complex) * kStepThreads * sizeof(R);
+  if (row_bytes > kRuntimeLdsLimit) return hipErrorNotSupported;
+  int device = 0;
+  if (hipError_t rc = hipGetDevice(&device); rc != hipSuccess) return rc;
+  static PerDevice<hipError_t> attr_measure;
+  hipError_t rc = attr_measure.get(device, [] {
+    return hipFuncSetAttribute((const void *)k_measure_runtime_cov<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRuntimeLdsLimit);
+  });
+  if (rc != hipSuccess) return rc;
+  const dim3 grid(grid_for(l.n, l.grid_blocks)), block(kStepThreads);
+  hipLaunchKernelGGL(k_measure_runtime_cov<R>, grid, block, row_bytes, stream, a, l.n_real, l.n_complex);
+  if (l.update_cov && l.write_factor) {
+    if (l.n_complex != 0) return hipErrorNotSupported;       // (me_create admits per-chain shapes for pure real spaces only)
+    auto launch = [&](auto rows_tag) -> hipError_t {
+      constexpr int ROWS = decltype(rows_tag)::value;
+      static PerDevice<hipError_t> attr_factor;
+      const hipError_t err = attr_factor.get(device, [] {
+        return hipFuncSetAttribute((const void *)k_factor_runtime<R, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRuntimeLdsLimit);
+      });
+      if (err != hipSuccess) return err;
+      hipLaunchKernelGGL((k_factor_runtime<R, ROWS>), grid, block, ROWS * row_bytes, stream, (const R *)l.cov, (R *)l.factor, l.status, l.n,
+                         l.n_real);
+      return hipGetLastError();
+    };
+    // as many rows together as the LDS admits: every finished row that is re-read serves all of them
+    if (4 * row_bytes <= kRuntimeLdsLimit) return launch(std::integral_constant<int, 4>{});
+    if (2 * row_bytes <= kRuntimeLdsLimit) return launch(std::integral_constant<int, 2>{});
+    return launch(std::integral_constant<int, 1>{});
+  }
   return hipGetLastError();
 }
 
@@ -621,10 +876,12 @@ hipError_t init_energy(const EnergyLaunch &l, hipStream_t stream) {
 }
 
 // n_real = n_complex = -1: the wildcard set find_kernel_set falls back to above kMaxRegisterDof (me_api.hip)
-const KernelSet kRuntimeF32 = {nullptr, ME_F32, -1, -1, false, false, has_energy, energy_terms, step<float>, nullptr,
-                               measure<float>, init_energy<float>, 0, nullptr, nullptr, false, false, nullptr, false};
-const KernelSet kRuntimeF64 = {nullptr, ME_F64, -1, -1, false, false, has_energy, energy_terms, step<double>, nullptr,
-                               measure<double>, init_energy<double>, 0, nullptr, nullptr, false, false, nullptr, false};
+// per_chain_cov / tracks_cov / streams_packed: the packed per-chain matrices are kept for cov_mode="reference" (pure real
+// spaces, me_create) or the tracking flag only, walked with 64-bit pointers, and may pass 4 GiB
+const KernelSet kRuntimeF32 = {nullptr, ME_F32, -1, -1, true, true, has_energy, energy_terms, step<float>, nullptr,
+                               measure<float>, init_energy<float>, 0, nullptr, nullptr, false, true, nullptr, false};
+const KernelSet kRuntimeF64 = {nullptr, ME_F64, -1, -1, true, true, has_energy, energy_terms, step<double>, nullptr,
+                               measure<double>, init_energy<double>, 0, nullptr, nullptr, false, true, nullptr, false};
 
 struct Registrar {
   Registrar() {

@@ -201,8 +201,9 @@ class MetropolisEngine:
                 # dimensions outside the prebuilt set: compile this (nr, nc) kernel set once (hipcc) and load it
                 _capi.check(self._lib.me_load_plugin(build.build_dims(nr, nc).encode()))
             elif build.MAX_REGISTER_DOF < d <= build.MAX_COMPILED_DOF and cov_mode == "reference":
-                # beyond 96 degrees of freedom the runtime-dimension set (no build) has no per-chain shapes: for the
-                # reference's semantics the space's own kernel set is compiled after all (streamed shapes, minutes of hipcc)
+                # beyond 96 degrees of freedom the runtime-dimension set (no build) has per-chain shapes for pure real spaces
+                # only, and slower ones: up to MAX_COMPILED_DOF the space's own kernel set is compiled after all for the
+                # reference's semantics (streamed shapes, real / mixed / complex spaces alike; minutes of hipcc, cached)
                 _capi.check(self._lib.me_load_plugin(build.build_dims(nr, nc).encode()))
         _capi.check(self._lib.me_create(ctypes.byref(cfg), ctypes.byref(handle)))
         self._handle = handle

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import metropolisengine_amd as me
+from metropolisengine_amd import build
 from oracle import energies
 from oracle.manychain import ManyChainOracle
 
@@ -168,8 +169,10 @@ def test_pooled_moments_and_adapt_pooled_shape_beyond_75_degrees_of_freedom(nr, 
 
 
 def test_unsupported_combinations_fail_loudly():
-    with pytest.raises(NotImplementedError, match="identity proposal shape"):
-        me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 150, None, temp=1.0, n_chains=8)      # cov_mode="reference"
+    with pytest.raises(NotImplementedError, match="identity proposal shape"):          # cov_mode="reference" with complex parameters
+        me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 100, [0j] * 30, temp=1.0, n_chains=8)
+    with pytest.raises(NotImplementedError, match="LDS"):                              # per-chain shapes: D x 64 values of LDS
+        me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 400, None, temp=1.0, n_chains=8, dtype="f64")
     with pytest.raises(NotImplementedError, match="LDS"):
         me.MetropolisEngine(me.DenseQuadratic(np.identity(700)), None, [0.0] * 700, None, temp=1.0, n_chains=8,
                             cov_mode="fixed")                                                  # x' would not fit in LDS
@@ -186,3 +189,76 @@ def test_unsupported_combinations_fail_loudly():
     eng = me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 120, None, temp=1.0, n_chains=8, cov_mode="fixed")
     with pytest.raises(NotImplementedError):
         eng.covariance_matrix_real
+
+
+@pytest.mark.parametrize("dtype,energy_kind", [("f64", "diag"), ("f64", "dense"), ("f32", "diag")])
+def test_per_chain_shapes_at_runtime_dimensions_follow_the_oracle(dtype, energy_kind):
+    """140 real parameters with the reference's default semantics (cov_mode="reference"): beyond build.MAX_COMPILED_DOF the
+    runtime-dimension set keeps the per-chain covariance (k_measure_runtime_cov), refreshes the per-chain factors
+    (k_factor_runtime) and draws x' = x + sigma L_chain g column by column (k_step_runtime_lds<CK_PER_CHAIN>) --
+    metropolis_engine.py:416-421 feeding :261-272 -- across the 50-measure threshold."""
+    nr, n, seed = 140, 70, 61
+    assert nr > build.MAX_COMPILED_DOF
+    x0 = list(np.linspace(-0.2, 0.2, nr))
+    if energy_kind == "diag":
+        weights = tuple(np.linspace(0.5, 2.0, nr))
+        energy, oracle_energy = me.DiagQuadratic(weights), energies.diag_quadratic(nr, 0, weights, ())
+    else:
+        m = np.random.default_rng(8).standard_normal((nr, nr))
+        amat = m @ m.T / nr + np.identity(nr)
+        energy, oracle_energy = me.DenseQuadratic(amat), energies.dense_quadratic(nr, 0, amat)
+    eng = me.MetropolisEngine(energy, None, x0, None, temp=1.0, n_chains=n, seed=seed, dtype=dtype, sampling_width=0.1)
+    assert eng.cov_mode == "reference"
+    if dtype == "f32":
+        # float32: the kernels run and the adaptive shapes are live (statistics, no trajectory parity at this length)
+        for k in range(56):
+            eng.step_all(2)
+            eng.measure()
+        fr, _ = eng.proposal_factors()
+        cov = eng.covariance_matrix_real
+        assert np.all(np.isfinite(fr)) and np.all(np.isfinite(cov))
+        assert np.allclose(np.einsum("cij,ckj->cik", fr, fr), cov, rtol=2e-3, atol=2e-5)      # factor = chol(cov), per chain
+        before = eng.accept_stats()
+        eng.step_all(5)
+        assert eng.accept_stats()[0] > before[0]
+        return
+    ora = ManyChainOracle(nr, 0, oracle_energy, n, seed=seed, temp=1.0, initial_real_params=x0, sampling_width=0.1)
+    for k in range(54):
+        eng.step_all(2)
+        ora.step(2)
+        eng.measure()
+        ora.measure()
+    fr, _ = eng.proposal_factors()
+    assert np.allclose(eng.real_mean, ora.mean[:, :nr], rtol=0, atol=1e-10)
+    assert np.allclose(eng.covariance_matrix_real, ora.cov_real, rtol=0, atol=1e-9)
+    assert np.allclose(fr, ora.factor_real, rtol=0, atol=1e-8)
+    for sweeps in (1, 3):
+        eng.step_all(sweeps)
+        ora.step(sweeps)
+    assert np.allclose(eng._get(0), ora.x, rtol=0, atol=1e-8)
+    assert np.allclose(eng.energy_total, ora.energy, rtol=0, atol=1e-8)
+    assert eng.accept_stats() == (ora.accepted, ora.proposed)
+    eng.measure()
+    ora.measure()
+    assert np.allclose(eng.covariance_matrix_real, ora.cov_real, rtol=0, atol=1e-9)
+
+
+def test_tracked_covariance_of_a_mixed_space_at_runtime_dimensions():
+    """100 real + 12 complex parameters (124 degrees of freedom), identity shape, track_covariance=True: the runtime-dimension
+    measure kernel keeps each chain's running covariance, real block and Hermitian block (metropolis_engine.py:416-427), as
+    statistics -- against the oracle across the 50-measure threshold."""
+    nr, nc, n, seed = 100, 12, 70, 13
+    real_w, cplx_w = tuple(np.linspace(0.5, 1.5, nr)), tuple(np.linspace(0.8, 1.2, nc))
+    x0, z0 = list(np.linspace(-0.1, 0.1, nr)), list(0.05 * np.exp(1j * np.arange(nc)))
+    eng = me.MetropolisEngine(me.DiagQuadratic(real_w, cplx_w), None, x0, z0, temp=1.0, n_chains=n, seed=seed, dtype="f64",
+                              sampling_width=0.05, cov_mode="fixed", track_covariance=True)
+    ora = ManyChainOracle(nr, nc, energies.diag_quadratic(nr, nc, real_w, cplx_w), n, seed=seed, temp=1.0,
+                          initial_real_params=x0, initial_complex_params=z0, sampling_width=0.05, adapt_shape=False)
+    for k in range(55):
+        eng.step_all(2)
+        ora.step(2)
+        eng.measure()
+        ora.measure()
+    assert np.allclose(eng.covariance_matrix_real, ora.cov_real, rtol=0, atol=1e-10)
+    assert np.allclose(eng.covariance_matrix_complex, ora.cov_complex, rtol=0, atol=1e-10)
+    assert not np.allclose(eng.covariance_matrix_real[0], np.identity(nr), atol=1e-4)
