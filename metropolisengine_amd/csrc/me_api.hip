@@ -442,11 +442,11 @@ int me_create(const me_config *c, me_engine **out) {
     return fail(nullptr, ME_ERR_UNSUPPORTED,
                 "ME_REJECT_USER: this user-energy plugin defines no me_user_reject (#define ME_USER_HAS_REJECT in its source)");
   if (ks->n_real < 0) {   // the runtime-dimension kernel set (me_runtime_dims.hip)
-    if ((c->cov_mode == ME_COV_REFERENCE || c->cov_mode == ME_COV_POOLED) && c->n_complex > 0)
+    if (c->cov_mode == ME_COV_POOLED && c->n_complex > 0)
       return fail(nullptr, ME_ERR_UNSUPPORTED,
                   "parameter spaces beyond " + std::to_string(kMaxRegisterDof) + " real degrees of freedom with complex "
-                  "parameters run with the identity proposal shape (ME_COV_FIXED, cov_mode=\"fixed\"); per-chain shapes "
-                  "(ME_COV_REFERENCE) and one shared factor (ME_COV_POOLED) are there for pure real spaces");
+                  "parameters run with the identity proposal shape (ME_COV_FIXED, cov_mode=\"fixed\") or per-chain shapes "
+                  "(ME_COV_REFERENCE); one shared factor (ME_COV_POOLED) is there for pure real spaces");
     // an initial covariance that is not the identity makes the engine start with a SHARED factor (cov_kind below), which the
     // runtime set has for pure real spaces only and which doubles the LDS a block needs
     const bool starts_shared = !initial_shape_is_identity(c);

@@ -20,16 +20,17 @@
 //                    Limits: the LDS a block may use (D <= ~290 in float64 with the identity shape, ~145 with a shared
 //                    factor; twice that in float32).
 //
-//   per-chain proposal shapes (ME_COV_REFERENCE, pure real spaces: the reference's semantics, :416-421 feeding :261-272):
-//                    k_measure_runtime_cov keeps each chain's running covariance (packed, tile-major, streamed),
-//                    k_factor_runtime refreshes its Cholesky factor row by row, and k_step_runtime_lds<CK_PER_CHAIN> forms
-//                    x' = x + sigma L_chain g by columns, four at a time, with only x' parked in LDS.  Written for
+//   per-chain proposal shapes (ME_COV_REFERENCE: the reference's semantics, :416-427 feeding :261-302):
+//                    k_measure_runtime_cov keeps each chain's running covariance (packed, tile-major, streamed; real block
+//                    and Hermitian block), k_factor_runtime / k_factor_runtime_complex refresh its Cholesky factors row by
+//                    row, and k_step_runtime_lds<CK_PER_CHAIN> forms x' = x + sigma L_chain g by columns (four real columns at
+//                    a time, complex columns one by one) with only x' parked in LDS.  Written for
 //                    completeness at any size the LDS admits (float64: 290 parameters), not for speed: a step reads the
 //                    chain's whole factor (D(D+1)/2 values), a refresh is D^3/6 dependent multiply-adds per lane.
 //
 // Supported: ME_ENERGY_ISO_QUAD, ME_ENERGY_DIAG_QUAD (streamed), ME_ENERGY_DENSE_QUAD (LDS); the identity proposal
-// shape (ME_COV_FIXED) and, for pure real spaces, one shared factor (ME_COV_POOLED) or per-chain shapes
-// (ME_COV_REFERENCE); running per-chain covariances for statistics (ME_FLAG_TRACK_COVARIANCE); the built-in wall, step_all and
+// shape (ME_COV_FIXED), per-chain shapes (ME_COV_REFERENCE) and, for pure real spaces, one shared factor
+// (ME_COV_POOLED); running per-chain covariances for statistics (ME_FLAG_TRACK_COVARIANCE); the built-in wall, step_all and
 // group-wise steps of mixed engines.  The word layout of a step is the one of every
 // other kernel (oracle/philox.py): normal i belongs to coordinate i, word 2 ceil(D/2) is the accept uniform.
 #include <type_traits>
@@ -268,12 +269,12 @@ __global__ void __launch_bounds__(kStepThreads) k_measure_runtime_cov(MeasureArg
 // dynamic LDS (rows[ROWS][nr][64]) -- Cholesky-Banachiewicz, each lane its own chain, finished rows re-read from the
 // factor field itself, ROWS rows built together so that every finished L_jk that is loaded serves ROWS dot products.
 template <typename R, int ROWS>
-__global__ void __launch_bounds__(kStepThreads) k_factor_runtime(const R *cov, R *factor, unsigned int *status, long long n, int nr) {
+__global__ void __launch_bounds__(kStepThreads) k_factor_runtime(const R *cov, R *factor, unsigned int *status, long long n, int nr,
+                                                                 long long P) {      // P: packed entries per chain (real + Hermitian block)
   using N_ = Num<R>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_rt[];
   R(*lds)[kStepThreads] = reinterpret_cast<R(*)[kStepThreads]>(smem_rt);
   auto row_of = [&](int r) { return lds + (size_t)r * nr; };          // rows[r][k][lane] = row_of(r)[k][lane]
-  const long long P = (long long)nr * (nr + 1) / 2;
   bool bad_pivot = false;
   const long long stride = (long long)gridDim.x * kStepThreads;
   const int lane = threadIdx.x;
@@ -340,6 +341,45 @@ __global__ void __launch_bounds__(kStepThreads) k_factor_runtime(const R *cov, R
         for (int j = 0; j <= i0 + r; ++j) dst[j * 64] = row_of(r)[j][lane];
       }
     }
+  }
+  if (bad_pivot) atomicOr(status, (unsigned int)ST_BAD_PIVOT);
+}
+
+// The Hermitian block of the factor at runtime dimensions: L = chol(conj K) (quirk Q3, metropolis_engine.py:292-298), the
+// complex half of k_factor_mixed (me_device.h) with runtime sizes -- row by row, each lane its own chain, every operand
+// through global memory (a finished L_ik is re-read from the factor field the lane itself wrote).  Written for
+// correctness, not speed.
+template <typename R>
+__global__ void __launch_bounds__(kStepThreads) k_factor_runtime_complex(const R *cov, R *factor, unsigned int *status, long long n, int nr,
+                                                                         int nc) {
+  using N_ = Num<R>;
+  const long long PR = (long long)nr * (nr + 1) / 2, P = PR + (long long)nc * nc;
+  bool bad_pivot = false;
+  const long long stride = (long long)gridDim.x * kStepThreads;
+  for (long long c = (long long)blockIdx.x * kStepThreads + threadIdx.x; c < n; c += stride) {
+    const long long base = (c >> 6) * P * 64 + (c & 63);
+    const R *cv = cov + base;
+    R *fc = factor + base;
+    auto re_at = [&](int i, int j) { return (PR + (long long)i * i + 2 * j) * 64; };      // cre; cim = + 64; cdiag = re_at(i, i)
+    for (int i = 0; i < nc; ++i)
+      for (int j = 0; j <= i; ++j) {
+        R sr = cv[re_at(i, j)];
+        R si = j < i ? -cv[re_at(i, j) + 64] : R(0);                // conj(K)
+        for (int k = 0; k < j; ++k) {                                // s -= L_ik conj(L_jk)
+          const R ar = fc[re_at(i, k)], ai = fc[re_at(i, k) + 64];
+          const R br = fc[re_at(j, k)], bi = fc[re_at(j, k) + 64];
+          sr = fma_(-ai, bi, fma_(-ar, br, sr));
+          si = fma_(ar, bi, fma_(-ai, br, si));
+        }
+        if (j < i) {
+          const R d = fc[re_at(j, j)];
+          fc[re_at(i, j)] = sr / d;
+          fc[re_at(i, j) + 64] = si / d;
+        } else {
+          if (!(sr > R(0))) { bad_pivot = true; sr = R(1e-30); }
+          fc[re_at(i, i)] = N_::sqrt_(sr);
+        }
+      }
   }
   if (bad_pivot) atomicOr(status, (unsigned int)ST_BAD_PIVOT);
 }
@@ -576,28 +616,64 @@ __global__ void __launch_bounds__(kStepThreads) k_step_runtime_lds(StepArgs<R> a
           if (d < D) {
             if constexpr (SHARED) gs[d][lane] = g[t];
             else if constexpr (CK == CK_PER_CHAIN) {
-              // (below, a whole Philox block at a time)
+              // real columns: below, a whole Philox block at a time.  A complex normal -- Re or Im part of zeta_j -- adds
+              // (w_c / sqrt 2) L_ij zeta_j to z'_i for the rows i >= j of the Hermitian block's factor L = chol(conj K)
+              // (:274-302; packed as (Re, Im) pairs of a row, then its real diagonal): column by column as well
+              if (d >= nr && d >= d0 && d < d1) {
+                const bool im_part = d >= nr + nc;
+                const int j = d - nr - (im_part ? nc : 0);
+                const long long pr = (long long)nr * (nr + 1) / 2;
+                const R *fac = a.factor + (c >> 6) * (pr + (long long)nc * nc) * 64 + (c & 63);
+                const R sc = s_c * g[t];
+                R(*zre)[kStepThreads] = xp + nr, (*zim)[kStepThreads] = xp + nr + nc;
+                // the diagonal entry is real: zeta's part goes to the same part of z'_j
+                (im_part ? zim : zre)[j][lane] = fma_(sc, fac[(pr + (long long)j * j + 2 * j) * 64], (im_part ? zim : zre)[j][lane]);
+                int i = j + 1;
+                for (; i + 8 <= nc; i += 8) {
+                  R lr[8], li[8];
+#pragma unroll
+                  for (int u = 0; u < 8; ++u) {
+                    const R *e2 = fac + (pr + (long long)(i + u) * (i + u) + 2 * j) * 64;
+                    lr[u] = e2[0];
+                    li[u] = e2[64];
+                  }
+#pragma unroll
+                  for (int u = 0; u < 8; ++u) {
+                    // (lr + i li) (sc) for a Re part, (lr + i li) (i sc) = -li sc + i lr sc for an Im part
+                    zre[i + u][lane] = fma_(im_part ? -sc : sc, im_part ? li[u] : lr[u], zre[i + u][lane]);
+                    zim[i + u][lane] = fma_(sc, im_part ? lr[u] : li[u], zim[i + u][lane]);
+                  }
+                }
+                for (; i < nc; ++i) {
+                  const R *e2 = fac + (pr + (long long)i * i + 2 * j) * 64;
+                  const R lr = e2[0], li = e2[64];
+                  zre[i][lane] = fma_(im_part ? -sc : sc, im_part ? li : lr, zre[i][lane]);
+                  zim[i][lane] = fma_(sc, im_part ? lr : li, zim[i][lane]);
+                }
+              }
             } else if (d >= d0 && d < d1) xp[d][lane] = fma_(d < nr ? s_r : s_c, g[t], xp[d][lane]);
           }
         }
         if constexpr (CK == CK_PER_CHAIN) {
-          // x' = x + w L g by COLUMNS (pure real spaces), four at a time: the normals of this Philox block add
+          // x' = x + w L g by COLUMNS for the real block, four at a time: the normals of this Philox block add
           // w (g_0 L_i,4b + ... + g_3 L_i,4b+3) to every row i >= 4 b.  Only x' has to be parked that way (row by row, all of g
           // would be needed as well); the four entries of a row are neighbours in the packed order, i.e. 4 x 64 values of the
           // wavefront's chains in one 2 KiB run of the tile-major factor field; sixteen loads (four rows) are issued together.
+          // (Rows i < nr only have columns <= i: a block that straddles the end of the real parameters needs no special case.)
           const int db = 4 * b;
+          if (db < nr && d0 == 0) {
           R sg[4];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) sg[t] = db + t < D ? s_r * g[t] : R(0);
-          const R *fac = a.factor + (c >> 6) * ((long long)D * (D + 1) / 2) * 64 + (c & 63);
-          for (int i = db; i < db + 4 && i < D; ++i) {        // the triangle on the diagonal: row i has columns 4 b .. i
+          for (int t = 0; t < 4; ++t) sg[t] = db + t < nr ? s_r * g[t] : R(0);
+          const R *fac = a.factor + (c >> 6) * ((long long)nr * (nr + 1) / 2 + (long long)nc * nc) * 64 + (c & 63);
+          for (int i = db; i < db + 4 && i < nr; ++i) {       // the triangle on the diagonal: row i has columns 4 b .. i
             const R *row = fac + (long long)tri(i, db) * 64;
             R acc = xp[i][lane];
             for (int t = 0; t <= i - db; ++t) acc = fma_(sg[t], row[t * 64], acc);
             xp[i][lane] = acc;
           }
           int i = db + 4;
-          for (; i + 4 <= D; i += 4) {
+          for (; i + 4 <= nr; i += 4) {
             R f[4][4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -613,12 +689,13 @@ __global__ void __launch_bounds__(kStepThreads) k_step_runtime_lds(StepArgs<R> a
               xp[i + u][lane] = acc;
             }
           }
-          for (; i < D; ++i) {
+          for (; i < nr; ++i) {
             const R *row = fac + (long long)tri(i, db) * 64;
             R acc = xp[i][lane];
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc = fma_(sg[t], row[t * 64], acc);
             xp[i][lane] = acc;
+          }
           }
         }
       }
@@ -747,7 +824,7 @@ int grid_of(long long n, int requested) {
 template <typename R>
 hipError_t step(const StepLaunch &l, hipStream_t stream) {
   if (l.inj_normals) return hipErrorNotSupported;
-  if (l.cov_kind != CK_IDENTITY && !((l.cov_kind == CK_SHARED || l.cov_kind == CK_PER_CHAIN) && l.n_complex == 0)) return hipErrorNotSupported;
+  if (l.cov_kind != CK_IDENTITY && l.cov_kind != CK_PER_CHAIN && !(l.cov_kind == CK_SHARED && l.n_complex == 0)) return hipErrorNotSupported;
   const bool mixed = l.n_real > 0 && l.n_complex > 0;
   if (l.group != GROUP_ALL && !mixed) return hipErrorInvalidValue;
   RuntimeStep<R> p;
@@ -841,7 +918,8 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
   const dim3 grid(grid_for(l.n, l.grid_blocks)), block(kStepThreads);
   hipLaunchKernelGGL(k_measure_runtime_cov<R>, grid, block, row_bytes, stream, a, l.n_real, l.n_complex);
   if (l.update_cov && l.write_factor) {
-    if (l.n_complex != 0) return hipErrorNotSupported;       // (me_create admits per-chain shapes for pure real spaces only)
+    const long long p_total = (long long)l.n_real * (l.n_real + 1) / 2 + (long long)l.n_complex * l.n_complex;
+    const size_t real_row_bytes = (size_t)l.n_real * kStepThreads * sizeof(R);
     auto launch = [&](auto rows_tag) -> hipError_t {
       constexpr int ROWS = decltype(rows_tag)::value;
       static PerDevice<hipError_t> attr_factor;
@@ -849,14 +927,20 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
         return hipFuncSetAttribute((const void *)k_factor_runtime<R, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRuntimeLdsLimit);
       });
       if (err != hipSuccess) return err;
-      hipLaunchKernelGGL((k_factor_runtime<R, ROWS>), grid, block, ROWS * row_bytes, stream, (const R *)l.cov, (R *)l.factor, l.status, l.n,
-                         l.n_real);
+      hipLaunchKernelGGL((k_factor_runtime<R, ROWS>), grid, block, ROWS * real_row_bytes, stream, (const R *)l.cov, (R *)l.factor, l.status,
+                         l.n, l.n_real, p_total);
       return hipGetLastError();
     };
-    // as many rows together as the LDS admits: every finished row that is re-read serves all of them
-    if (4 * row_bytes <= kRuntimeLdsLimit) return launch(std::integral_constant<int, 4>{});
-    if (2 * row_bytes <= kRuntimeLdsLimit) return launch(std::integral_constant<int, 2>{});
-    return launch(std::integral_constant<int, 1>{});
+    if (l.n_real > 0) {
+      // as many rows together as the LDS admits: every finished row that is re-read serves all of them
+      const hipError_t err = 4 * real_row_bytes <= kRuntimeLdsLimit   ? launch(std::integral_constant<int, 4>{})
+                             : 2 * real_row_bytes <= kRuntimeLdsLimit ? launch(std::integral_constant<int, 2>{})
+                                                                      : launch(std::integral_constant<int, 1>{});
+      if (err != hipSuccess) return err;
+    }
+    if (l.n_complex > 0)
+      hipLaunchKernelGGL(k_factor_runtime_complex<R>, grid, block, 0, stream, (const R *)l.cov, (R *)l.factor, l.status, l.n, l.n_real,
+                         l.n_complex);
   }
   return hipGetLastError();
 }

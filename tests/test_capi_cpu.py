@@ -160,8 +160,8 @@ def test_per_device_cache_is_keyed_by_device(tmp_path):
 
 def test_runtime_dimension_kernel_set_is_the_fallback_beyond_96_dof():
     """Parameter spaces beyond the register-resident kernels (n_real + 2 n_complex > 96) resolve to the runtime-dimension
-    set of the main library (csrc/me_runtime_dims.hip): separable and dense energies; identity shape, one shared factor or
-    per-chain shapes for pure real spaces, the identity shape with complex parameters."""
+    set of the main library (csrc/me_runtime_dims.hip): separable and dense energies; identity shape or per-chain shapes, and one
+    shared factor for pure real spaces."""
     lib = _capi.load()
     assert lib.me_supported(_capi.ME_F32, 200, 0, _capi.ENERGY_ISO_QUAD) == 1
     assert lib.me_supported(_capi.ME_F64, 60, 25, _capi.ENERGY_DIAG_QUAD) == 1
@@ -178,7 +178,9 @@ def test_runtime_dimension_kernel_set_is_the_fallback_beyond_96_dof():
     handle = ctypes.c_void_p()
     cfg.cov_mode = _capi.COV_REFERENCE
     assert lib.me_create(ctypes.byref(cfg), ctypes.byref(handle)) == _capi.ME_ERR_HIP     # per-chain shapes, pure real: accepted; no GPU here
-    cfg.n_real, cfg.n_complex = 100, 50                                                  # ... with complex parameters: identity only
+    cfg.n_real, cfg.n_complex = 100, 50                                                  # ... with complex parameters as well
+    assert lib.me_create(ctypes.byref(cfg), ctypes.byref(handle)) == _capi.ME_ERR_HIP
+    cfg.cov_mode = _capi.COV_POOLED                                                      # ... but no shared factor there
     assert lib.me_create(ctypes.byref(cfg), ctypes.byref(handle)) == _capi.ME_ERR_UNSUPPORTED
     assert "identity proposal shape" in _capi.last_error()
     cfg.n_real, cfg.n_complex = 200, 0

@@ -146,13 +146,14 @@ def test_largest_register_resident_dimension():
     assert 0.15 < eng.acceptance_rate() < 0.5
     eng.measure()
     assert np.allclose(eng.real_mean[0], (x[0] + 0.0) / 2, atol=1e-6)      # mean of the initial point and the state
-    # beyond build.MAX_COMPILED_DOF the default cov_mode (per-chain shapes) runs on the runtime-dimension set for pure real spaces
+    # beyond build.MAX_COMPILED_DOF the default cov_mode (per-chain shapes) runs on the runtime-dimension set
     big = me.MetropolisEngine(me.IsoQuadratic(a), initial_real_params=[0.0] * 200, temp=1.0, n_chains=64)
     big.step_all(2)
     big.measure()
     assert big.cov_mode == "reference" and big.covariance_matrix_real.shape == (64, 200, 200)
-    with pytest.raises(RuntimeError):               # ... and is refused with complex parameters
-        me.MetropolisEngine(me.IsoQuadratic(a), initial_real_params=[0.0] * 100, initial_complex_params=[0j] * 50, temp=1.0, n_chains=64)
+    with pytest.raises(RuntimeError):               # ... what it does not have there is one shared factor for spaces with complex parameters
+        me.MetropolisEngine(me.IsoQuadratic(a), initial_real_params=[0.0] * 100, initial_complex_params=[0j] * 50, temp=1.0, n_chains=64,
+                            cov_mode="pooled")
 
 
 def test_split_pooled_moments_report_the_state_at_begin():

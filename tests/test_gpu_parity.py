@@ -364,8 +364,8 @@ def test_pooled_shared_covariance_mode():
 
 def test_errors_on_gpu():
     with pytest.raises(NotImplementedError, match="identity proposal shape"):      # runtime-dimension kernels (beyond
-        me.MetropolisEngine(me.IsoQuadratic(), initial_real_params=[0.0] * 100, initial_complex_params=[0j] * 30, temp=1.0)
-    #                    build.MAX_COMPILED_DOF nothing is compiled on demand): with complex parameters cov_mode="fixed" only
+        me.MetropolisEngine(me.IsoQuadratic(), initial_real_params=[0.0] * 100, initial_complex_params=[0j] * 30, temp=1.0,
+                            cov_mode="pooled")      # build.MAX_COMPILED_DOF): no shared factor with complex parameters
     ref = me.MetropolisEngine(me.IsoQuadratic(), initial_real_params=[0.0] * 64, temp=1.0, n_chains=64)   # streamed per-chain
     assert ref.covariance_matrix_real.shape == (64, 64, 64)                                              # shapes (reference mode)
     eng = me.MetropolisEngine(me.IsoQuadratic(), initial_real_params=[0.0] * 64, temp=1.0, cov_mode="fixed",

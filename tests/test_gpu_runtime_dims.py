@@ -169,8 +169,8 @@ def test_pooled_moments_and_adapt_pooled_shape_beyond_75_degrees_of_freedom(nr, 
 
 
 def test_unsupported_combinations_fail_loudly():
-    with pytest.raises(NotImplementedError, match="identity proposal shape"):          # cov_mode="reference" with complex parameters
-        me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 100, [0j] * 30, temp=1.0, n_chains=8)
+    with pytest.raises(NotImplementedError, match="identity proposal shape"):          # one shared factor with complex parameters
+        me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 100, [0j] * 30, temp=1.0, n_chains=8, cov_mode="pooled")
     with pytest.raises(NotImplementedError, match="LDS"):                              # per-chain shapes: D x 64 values of LDS
         me.MetropolisEngine(me.IsoQuadratic(1.0), None, [0.0] * 400, None, temp=1.0, n_chains=8, dtype="f64")
     with pytest.raises(NotImplementedError, match="LDS"):
@@ -262,3 +262,45 @@ def test_tracked_covariance_of_a_mixed_space_at_runtime_dimensions():
     assert np.allclose(eng.covariance_matrix_real, ora.cov_real, rtol=0, atol=1e-10)
     assert np.allclose(eng.covariance_matrix_complex, ora.cov_complex, rtol=0, atol=1e-10)
     assert not np.allclose(eng.covariance_matrix_real[0], np.identity(nr), atol=1e-4)
+
+
+@pytest.mark.parametrize("nr,nc", [(100, 20), (0, 70)], ids=["mixed", "complex"])
+def test_per_chain_shapes_of_mixed_and_complex_spaces_at_runtime_dimensions(nr, nc):
+    """140 degrees of freedom with complex parameters, cov_mode="reference": the Hermitian block's running covariance
+    (:423-427), L = chol(conj K) (quirk Q3, :292-298, k_factor_runtime_complex) and z' = z + (sigma_c / sqrt 2) L zeta column by
+    column (:274-302) -- step_all and, for the mixed space, group-wise steps -- against the oracle across the threshold."""
+    n, seed = 70, 71
+    assert nr + 2 * nc > build.MAX_COMPILED_DOF
+    real_w, cplx_w = tuple(np.linspace(0.5, 2.0, nr)), tuple(np.linspace(0.7, 1.6, nc))
+    x0 = list(np.linspace(-0.2, 0.2, nr)) if nr else None
+    z0 = list(0.1 * np.exp(0.7j * np.arange(nc)))
+    eng = me.MetropolisEngine(me.DiagQuadratic(real_w, cplx_w), None, x0, z0, temp=1.0, n_chains=n, seed=seed, dtype="f64",
+                              sampling_width=0.08)
+    ora = ManyChainOracle(nr, nc, energies.diag_quadratic(nr, nc, real_w, cplx_w), n, seed=seed, temp=1.0,
+                          initial_real_params=x0, initial_complex_params=z0, sampling_width=0.08)
+    assert eng.cov_mode == "reference"
+    for k in range(54):
+        eng.step_all(2)
+        ora.step(2)
+        eng.measure()
+        ora.measure()
+    fr, fc = eng.proposal_factors()
+    assert np.allclose(eng.covariance_matrix_complex, ora.cov_complex, rtol=0, atol=1e-9)
+    assert np.allclose(fc, ora.factor_complex, rtol=0, atol=1e-8)
+    if nr:
+        assert np.allclose(eng.covariance_matrix_real, ora.cov_real, rtol=0, atol=1e-9)
+        assert np.allclose(fr, ora.factor_real, rtol=0, atol=1e-8)
+    for sweeps in (1, 3):
+        eng.step_all(sweeps)
+        ora.step(sweeps)
+    assert np.allclose(eng._get(0), ora.x, rtol=0, atol=1e-8)
+    assert eng.accept_stats() == (ora.accepted, ora.proposed)
+    if nr:
+        for group in ("real", "complex", "real"):
+            getattr(eng, "step_%s_group" % group)()
+            ora.step(1, group=group)
+        assert np.allclose(eng._get(0), ora.x, rtol=0, atol=1e-8)
+        assert eng.accept_stats() == (ora.accepted, ora.proposed)
+    eng.measure()
+    ora.measure()
+    assert np.allclose(eng.covariance_matrix_complex, ora.cov_complex, rtol=0, atol=1e-9)
