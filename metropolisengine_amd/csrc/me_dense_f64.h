@@ -385,7 +385,9 @@ __global__ void __launch_bounds__(kDense64F64Threads, 2)
     bad_width |= live && !(w > 0.0);
     // The prefetch was issued a tile of arithmetic ago: wait for it BEFORE this tile's stores are queued behind it (vmcnt
     // counts in order; afterwards any wait on the prefetch would drain the stores as well).
-    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
+    // (an asm with a memory clobber, not the builtin: the compiler must not move the reads of the slab above this wait -- it
+    // does not know that the load unit writes LDS behind its back)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     {
       const unsigned int off = state_off(tile);
 #pragma unroll
@@ -404,7 +406,7 @@ __global__ void __launch_bounds__(kDense64F64Threads, 2)
 #elif ME_DENSE64_F64_PREFETCH == 2
 #pragma unroll
       for (int ks = 0; ks < S; ++ks) x[ks] = *reinterpret_cast<const f64x2 *>(slab + ks * 128 + lane * 2);
-      __builtin_amdgcn_s_waitcnt(0xC07F);    // lgkmcnt(0): the slab is free for the next prefetch
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the slab has been read: free for the next prefetch
 #else
       load_rows(next, x);
       __builtin_amdgcn_s_waitcnt(0x0F70);

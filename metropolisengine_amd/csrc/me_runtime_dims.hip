@@ -296,7 +296,74 @@ __global__ void __launch_bounds__(kStepThreads) k_factor_runtime(const R *cov, R
         }
         for (; j <= i0 + r; ++j) row_of(r)[j][lane] = src[j * 64];
       }
-      for (int j = 0; j < i0; ++j) {                       // columns left of the block: row j serves all rows of the block
+      // Columns left of the block: finished row j serves all rows of the block.  The walk is bound by memory LATENCY (one
+      // wavefront per SIMD at most, every batch of loads a round trip), and column j needs column j - 1 of the block's rows:
+      // FOUR finished rows are therefore fetched together -- their first j entries in batches of 4 x 16 loads, then the ten
+      // entries of the little triangle between them -- and the four columns are finished one after the other from registers.
+      int j = 0;
+      for (; j + 4 <= i0; j += 4) {
+        const R *lj[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lj[q] = fc + (long long)tri(j + q, 0) * 64;
+        R sum[4][ROWS];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) sum[q][r] = R(0);
+        int k = 0;
+        for (; k + 16 <= j; k += 16) {
+          R f[4][16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) f[q][u] = lj[q][(k + u) * 64];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            R v[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) v[r] = r < nrows ? row_of(r)[k + u][lane] : R(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int r = 0; r < ROWS; ++r) sum[q][r] += v[r] * f[q][u];
+          }
+        }
+        for (; k < j; k += 4) {                             // (j is a multiple of 4)
+          R f[4][4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) f[q][u] = lj[q][(k + u) * 64];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            R v[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) v[r] = r < nrows ? row_of(r)[k + u][lane] : R(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int r = 0; r < ROWS; ++r) sum[q][r] += v[r] * f[q][u];
+          }
+        }
+        R t[4][4];                                          // L[j + q][j + p], p <= q
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int p = 0; p <= q; ++p) t[q][p] = lj[q][(j + p) * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const R inv = R(1) / t[q][q];
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r)
+            if (r < nrows) {
+              R acc = sum[q][r];
+#pragma unroll
+              for (int p = 0; p < q; ++p) acc += row_of(r)[j + p][lane] * t[q][p];
+              row_of(r)[j + q][lane] = (row_of(r)[j + q][lane] - acc) * inv;
+            }
+        }
+      }
+      for (; j < i0; ++j) {                                 // (at most three rows left)
         const R *lj = fc + (long long)tri(j, 0) * 64;
         R sum[ROWS];
 #pragma unroll
