@@ -1490,8 +1490,8 @@ __global__ void __launch_bounds__(kStepThreads) k_factor(const R *cov, R *factor
 // Per-chain Cholesky factor of a covariance matrix too large for registers (more than 160 packed entries; pure real
 // spaces): factor = chol(C), row by row (Cholesky-Banachiewicz), each lane its own chain, everything through global
 // memory in the tile-major layout -- L_ij = (C_ij - sum_{k<j} L_ik L_jk) / L_jj.  The row being built lives in LDS
-// ([NR][64 lanes], lane-linear); the finished rows are re-read from the factor field itself, in batches of 32 (then 8)
-// loads issued ahead of their multiply-adds.  ROWS rows are built together so that every finished L_jk that is loaded serves
+// ([NR][64 lanes], lane-linear); the finished rows are re-read from the factor field itself, four rows at a time in
+// batches of 4 x 16 loads issued ahead of their multiply-adds.  ROWS rows are built together so that every finished L_jk that is loaded serves
 // ROWS dot products: the traffic is NR^3 / (6 ROWS) loads per chain (64 parameters, ROWS = 4: 11 k loads = 44 KB in
 // float32).  Slow by construction -- an order of magnitude above a measure() with the pooled shape -- and there only
 // so that cov_mode="reference" keeps the reference's semantics (metropolis_engine.py:416-421 feeding :268-270) at any
@@ -1524,22 +1524,80 @@ __global__ void __launch_bounds__(kStepThreads) k_factor_stream(const R *cov, R 
         }
         for (; j <= i0 + r; ++j) rows[r][j][lane] = NT ? __builtin_nontemporal_load(src + j * 64) : src[j * 64];
       }
-      // columns left of the block: every finished row j < i0 serves all rows of the block
-      for (int j = 0; j < i0; ++j) {
+      // Columns left of the block: every finished row j < i0 serves all rows of the block.  The walk is bound by memory
+      // LATENCY (every batch of loads a round trip, and column j needs column j - 1 of the block's rows): FOUR finished rows
+      // are fetched together -- their first j entries in batches of 4 x 16 loads, then the ten entries of the little triangle
+      // between them -- and the four columns are finished one after the other from registers (round 3; one row per visit
+      // with two or three dependent round trips each took twice as long: 8.0 -> 4.5 ms per measure at 100 parameters x 2^14
+      // chains in float64, tools/dev/time_compiled_vs_runtime.py).
+      int j = 0;
+      for (; j + 4 <= i0; j += 4) {
+        const R *lj[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lj[q] = fc + (long long)tri(j + q, 0) * 64;
+        R s[4][ROWS];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) s[q][r] = R(0);
+        int k = 0;
+        for (; k + 16 <= j; k += 16) {
+          R f[4][16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) f[q][u] = lj[q][(k + u) * 64];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            R v[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) v[r] = rows[r][k + u][lane];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int r = 0; r < ROWS; ++r) s[q][r] += v[r] * f[q][u];
+          }
+        }
+        for (; k < j; k += 4) {                             // (j is a multiple of 4)
+          R f[4][4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) f[q][u] = lj[q][(k + u) * 64];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            R v[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) v[r] = rows[r][k + u][lane];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int r = 0; r < ROWS; ++r) s[q][r] += v[r] * f[q][u];
+          }
+        }
+        R t[4][4];                                          // L[j + q][j + p], p <= q
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int p = 0; p <= q; ++p) t[q][p] = lj[q][(j + p) * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const R inv = R(1) / t[q][q];
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) {
+            R acc = s[q][r];
+#pragma unroll
+            for (int p = 0; p < q; ++p) acc += rows[r][j + p][lane] * t[q][p];
+            rows[r][j + q][lane] = (rows[r][j + q][lane] - acc) * inv;
+          }
+        }
+      }
+      for (; j < i0; ++j) {                                 // (at most three rows left)
         const R *lj = fc + (long long)tri(j, 0) * 64;
         R s[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) s[r] = R(0);
         int k = 0;
-        for (; k + 32 <= j; k += 32) {
-          R f[32];
-#pragma unroll
-          for (int u = 0; u < 32; ++u) f[u] = lj[(k + u) * 64];
-#pragma unroll
-          for (int u = 0; u < 32; ++u)
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) s[r] += rows[r][k + u][lane] * f[u];
-        }
         for (; k + 8 <= j; k += 8) {
           R f[8];
 #pragma unroll
