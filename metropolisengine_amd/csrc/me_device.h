@@ -334,34 +334,23 @@ struct EnergyIso {  // a (sum x^2 + sum |z|^2)                                  
 template <typename R, int NR, int NC>
 struct EnergyDiag {  // sum a_i x_i^2 + sum b_j |z_j|^2; weights expanded to D entries on the host
   static constexpr int D = NR + 2 * NC;
+  // The weights arrive as kernel arguments, i.e. in scalar registers: 2 D of them in float64.  At 16 parameters they no
+  // longer fit beside the Philox keys and the field descriptors; the spilled ones come back through v_readlane in the middle
+  // of the Box-Muller blocks, the scheduler gives up the occupancy it reaches for EnergyIso, and k_step<double,16,0,identity>
+  // takes 171 vector registers (two wavefronts per SIMD) against 120 (four) -- forced to four it spills 44 bytes per lane.
+  // Staging the weights in LDS (read back as broadcasts inside the sweep loop, behind a compiler barrier so that they are
+  // not hoisted into registers again) was tried in round 3: 133 registers and 55 -> 54 us for that kernel, but the barrier
+  // sits in every sweep of k_cycle too, whose packed matrix lives in registers across the sweeps: cycle(10) at (16,0) in
+  // float64 1.4 -> 9.6 ms, config 3's cycle 3.1 -> 1.9 x 10^10 chain-steps/s.  Not kept.
   R w[D];
-  // The weights arrive as kernel arguments, i.e. in scalar registers: 2 D of them in float64.  From 16 parameters on they
-  // no longer fit beside the Philox keys and the field descriptors; the spilled ones come back through v_readlane in the
-  // middle of the Box-Muller blocks, the scheduler gives up the occupancy it reaches for EnergyIso and the kernel takes 171
-  // vector registers (two wavefronts per SIMD) against 120 (four) -- forced to four it spills 44 bytes per lane.  Beyond 64
-  // bytes of weights they are staged in LDS once per block instead and read back as broadcasts, one per multiply-add.
-  static constexpr bool kStaged = sizeof(R) * D > 64;
-  static __device__ __forceinline__ R *staged() {
-    __shared__ R t[kStaged ? D : 1];
-    return t;
-  }
-  __device__ __forceinline__ void prepare() const {
-    if constexpr (kStaged) {
-      R *t = staged();
-      for (int d = threadIdx.x; d < D; d += (int)blockDim.x) t[d] = w[d];
-      __syncthreads();
-    }
-  }
   __device__ __forceinline__ R operator()(const R (&x)[D]) const {
-    const R *wt = kStaged ? staged() : w;
-    if constexpr (kStaged) asm volatile("" ::: "memory");      // (the reads stay inside the sweep loop: see EnergyDense)
     R s0 = 0, s1 = 0;   // two interleaved chains (see EnergyIso)
 #pragma unroll
     for (int d = 0; d + 1 < D; d += 2) {
-      s0 += wt[d] * x[d] * x[d];
-      s1 += wt[d + 1] * x[d + 1] * x[d + 1];
+      s0 += w[d] * x[d] * x[d];
+      s1 += w[d + 1] * x[d + 1] * x[d + 1];
     }
-    if constexpr (D % 2 == 1) s0 += wt[D - 1] * x[D - 1] * x[D - 1];
+    if constexpr (D % 2 == 1) s0 += w[D - 1] * x[D - 1] * x[D - 1];
     return s0 + s1;
   }
 };
