@@ -9,6 +9,7 @@
 #include <cstdio>
 
 constexpr int P = 136, D = 16, NOBS = 32;
+using d2 = __attribute__((ext_vector_type(2))) double;
 
 template <int BATCH>
 __global__ void __launch_bounds__(64) k_measure_pattern(const double *x, const double *w, double *mean, double *obs, double *cov, double *fac, long long n) {
@@ -66,6 +67,43 @@ __global__ void __launch_bounds__(64) k_step_pattern(double *state, const double
   for (int d = 0; d < D + 2; ++d) state[d * n + c] = xs[d] + s * 1e-30;
 }
 
+// the same measure pattern with the packed fields as ENTRY PAIRS, [tile of 64][P / 2][64 lanes][2]: 16-byte accesses,
+// half as many memory instructions (would the floor move?  the dense 64-parameter state gained 15 % that way, the
+// 16-parameter state nothing: tools/dev/state_layout_probe64.hip, rows_probe_f64_tiled.hip)
+template <int BATCH>
+__global__ void __launch_bounds__(64) k_measure_pattern_pairs(const double *x, const double *w, double *mean, double *obs, d2 *cov, d2 *fac, long long n) {
+  const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (c >= n) return;
+  double xs[D], mu[D], ob[NOBS];
+#pragma unroll
+  for (int d = 0; d < D; ++d) xs[d] = x[d * n + c];
+#pragma unroll
+  for (int d = 0; d < D; ++d) mu[d] = mean[d * n + c];
+  double acc = w[c];
+#pragma unroll
+  for (int d = 0; d < D; ++d) mean[d * n + c] = mu[d] * 0.99 + xs[d] * 0.01;
+#pragma unroll
+  for (int k = 0; k < NOBS; ++k) ob[k] = obs[k * n + c];
+#pragma unroll
+  for (int k = 0; k < NOBS; ++k) obs[k * n + c] = ob[k] * 0.99 + xs[k & 15] * 0.01;
+  constexpr int P2 = P / 2;
+  d2 *pc = cov + (c >> 6) * (long long)P2 * 64 + (c & 63), *pf = fac + (c >> 6) * (long long)P2 * 64 + (c & 63);
+#pragma unroll
+  for (int k0 = 0; k0 < P2; k0 += BATCH) {
+    d2 m[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u)
+      if (k0 + u < P2) m[u] = __builtin_nontemporal_load(pc + (k0 + u) * 64);
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u)
+      if (k0 + u < P2) {
+        const d2 v = m[u] * 0.98 + acc * 1e-30;
+        __builtin_nontemporal_store(v, pc + (k0 + u) * 64);
+        __builtin_nontemporal_store(v + 1.0, pf + (k0 + u) * 64);
+      }
+  }
+}
+
 template <class F>
 float time_it(F &&launch) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -89,6 +127,9 @@ int main() {
 #define RUN_S(B) { const float us = time_it([&] { hipLaunchKernelGGL(k_step_pattern<B>, dim3((unsigned)(n / 64)), dim3(64), 0, 0, x, fac, n); }); \
     printf("k_step<double,16,0,per-chain> pattern, %3d entries in flight: %7.1f us  %5.0f GB/s  (%.3f of 8 TB/s)\n", B, us, step_bytes / us / 1e3, step_bytes / us / 8e6); }
   RUN_M(136) RUN_M(68) RUN_M(32) RUN_M(16)
+#define RUN_P(B) { const float us = time_it([&] { hipLaunchKernelGGL(k_measure_pattern_pairs<B>, dim3((unsigned)(n / 64)), dim3(64), 0, 0, x, w, mean, obs, (d2 *)cov, (d2 *)fac, n); }); \
+    printf("k_measure<double,16,0> pattern, 16-byte entry pairs, %3d pairs in flight: %7.1f us  %5.0f GB/s  (%.3f of 8 TB/s)\n", B, us, measure_bytes / us / 1e3, measure_bytes / us / 8e6); }
+  RUN_P(68) RUN_P(34) RUN_P(16)
   RUN_S(136) RUN_S(68) RUN_S(32) RUN_S(16)
   printf("algorithmic bytes per launch: measure %.0f MB, step %.0f MB\n", measure_bytes / 1e6, step_bytes / 1e6);
   return 0;
