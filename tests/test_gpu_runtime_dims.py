@@ -304,3 +304,23 @@ def test_per_chain_shapes_of_mixed_and_complex_spaces_at_runtime_dimensions(nr, 
     eng.measure()
     ora.measure()
     assert np.allclose(eng.covariance_matrix_complex, ora.cov_complex, rtol=0, atol=1e-9)
+
+
+def test_runtime_per_chain_fields_beyond_4_gib_are_addressed_correctly():
+    """140 real parameters x 2^16 chains in float64: each packed per-chain field is 9 870 x 8 B x 65 536 = 5.2 GB.  The last chains
+    of the big engine equal a small engine that owns the same global chain ids -- covariance recursion, factor refresh and the
+    column-wise proposal all walk the fields with 64-bit pointers (same Philox streams, same arithmetic: bitwise)."""
+    nr, n = 140, 1 << 16
+    kw = dict(temp=1.0, seed=17, sampling_width=0.08, dtype="f64")
+    weights = tuple(np.linspace(0.5, 2.0, nr))
+    lo, cnt = n - 200, 200
+    big = me.MetropolisEngine(me.DiagQuadratic(weights), None, [0.0] * nr, None, n_chains=n, **kw)
+    small = me.MetropolisEngine(me.DiagQuadratic(weights), None, [0.0] * nr, None, n_chains=cnt, chain_offset=lo, **kw)
+    for eng in (big, small):
+        for k in range(52):
+            eng.step_all(1)
+            eng.measure()
+        eng.step_all(2)
+    assert np.array_equal(big._get(0)[lo:], small._get(0))
+    assert np.array_equal(big.energy_total[lo:], small.energy_total)
+    assert np.array_equal(big.real_group_sampling_width[lo:], small.real_group_sampling_width)
