@@ -404,6 +404,9 @@ MeasureArgs<R> typed_measure(const MeasureLaunch &l) {
 // n_sweeps x step_all + measure in one launch (k_cycle, me_device.h) for the kernel sets whose packed matrix lives in
 // registers; anything else -- group steps, injected streams, a shared factor, engines that keep no per-chain covariance,
 // the matrix-core kernels of the dense 64-parameter form -- answers hipErrorNotSupported and me_cycle issues two launches.
+#ifndef ME_FACTOR_TILE
+#define ME_FACTOR_TILE 1      // 0 (dev): the one-lane-per-chain k_factor_stream also for 64 parameters and fewer
+#endif
 #ifndef ME_CYCLE
 #define ME_CYCLE (ME_PER_CHAIN == 1)
 #endif
@@ -477,7 +480,7 @@ hipError_t measure(const MeasureLaunch &l, hipStream_t stream) {
     if constexpr (NC > 0) {       // a complex block: the plain one-lane-per-chain form (k_factor_mixed, me_device.h)
       if (nt) hipLaunchKernelGGL((k_factor_mixed<R, NR, NC, true>), grid, block, 0, stream, (const R *)l.cov, (R *)l.factor, l.status, l.n);
       else hipLaunchKernelGGL((k_factor_mixed<R, NR, NC, false>), grid, block, 0, stream, (const R *)l.cov, (R *)l.factor, l.status, l.n);
-    } else if constexpr (NR <= 64) {     // a lane group per chain, a lane per row: every matrix read once (me_factor_tile.h)
+    } else if constexpr (NR <= 64 && ME_FACTOR_TILE) {     // a lane group per chain, a lane per row: every matrix read once (me_factor_tile.h)
       const hipError_t err = nt ? launch_factor_tile<R, NR, true>((const R *)l.cov, (R *)l.factor, l.status, l.n, stream)
                                 : launch_factor_tile<R, NR, false>((const R *)l.cov, (R *)l.factor, l.status, l.n, stream);
       if (err != hipSuccess) return err;
