@@ -81,6 +81,10 @@ typedef enum me_cov_mode {
   ME_COV_FIXED = 1,     /* keep the initial matrix for ever (measure() still updates the statistics) */
   ME_COV_POOLED = 2     /* one factor shared by all chains, installed with me_set_shared_factor */
 } me_cov_mode;
+/* Availability: every mode for every parameter space up to 96 real degrees of freedom (n_real + 2 n_complex; plugins and
+   kernel sets compiled for one size: any size).  Beyond that -- the runtime-dimension kernel set -- ME_COV_FIXED and
+   ME_COV_REFERENCE for every space whose D x 64 values fit the LDS (float64: D <= 290), ME_COV_POOLED for pure real spaces
+   (two such blocks: D <= 145 in float64); me_create answers ME_ERR_UNSUPPORTED otherwise. */
 
 /* Per-chain fields for me_get / me_set; components per chain in brackets (P = nr(nr+1)/2 + nc^2). */
 typedef enum me_field {
