@@ -449,7 +449,9 @@ int me_create(const me_config *c, me_engine **out) {
                   "(ME_COV_REFERENCE); one shared factor (ME_COV_POOLED) is there for pure real spaces");
     // an initial covariance that is not the identity makes the engine start with a SHARED factor (cov_kind below), which the
     // runtime set has for pure real spaces only and which doubles the LDS a block needs
-    const bool starts_shared = !initial_shape_is_identity(c);
+    // (with ME_COV_REFERENCE the per-chain factor field exists and is filled with the initial factor: such an engine starts
+    // with per-chain shapes right away, which every space has and which park x' only)
+    const bool starts_shared = !initial_shape_is_identity(c) && c->cov_mode != ME_COV_REFERENCE;
     if (starts_shared && c->n_complex > 0)
       return fail(nullptr, ME_ERR_UNSUPPORTED,
                   "parameter spaces beyond " + std::to_string(kMaxRegisterDof) + " real degrees of freedom with complex "
@@ -464,7 +466,7 @@ int me_create(const me_config *c, me_engine **out) {
         return fail(nullptr, ME_ERR_UNSUPPORTED,
                     "a dense quadratic form, a shared proposal factor or per-chain shapes beyond " + std::to_string(kMaxRegisterDof) +
                         " degrees of freedom are staged in LDS: this many parameters do not fit (float64: about 290, 145 with "
-                        "a shared factor or an initial covariance; float32 twice that)");
+                        "a shared factor or an initial covariance that ME_COV_FIXED keeps; float32 twice that)");
     }
     if (c->flags & ME_FLAG_REFERENCE_ENERGY_LEDGERS)
       return fail(nullptr, ME_ERR_UNSUPPORTED, "ME_FLAG_REFERENCE_ENERGY_LEDGERS is not available beyond " +
@@ -673,7 +675,10 @@ int me_create(const me_config *c, me_engine **out) {
     release(e);
     return ME_ERR_HIP;
   }
-  e->cov_kind = identity ? CK_IDENTITY : CK_SHARED;
+  // a non-identity initial shape is ONE factor for all chains; the runtime-dimension set reads it from the per-chain field
+  // (every chain's copy was written above) when the engine keeps one -- its shared-factor form is for pure real spaces
+  // only and needs twice the LDS
+  e->cov_kind = identity ? CK_IDENTITY : (ks->n_real < 0 && e->factor) ? CK_PER_CHAIN : CK_SHARED;
 
   rc = me_recompute_energy(e);
   if (rc == ME_OK) {

@@ -324,3 +324,39 @@ def test_runtime_per_chain_fields_beyond_4_gib_are_addressed_correctly():
     assert np.array_equal(big._get(0)[lo:], small._get(0))
     assert np.array_equal(big.energy_total[lo:], small.energy_total)
     assert np.array_equal(big.real_group_sampling_width[lo:], small.real_group_sampling_width)
+
+
+def test_initial_covariance_with_per_chain_shapes_at_runtime_dimensions():
+    """cov_mode="reference" with covariance_matrix_real / _complex given (the reference's warm start, metropolis_engine.py:17-24,
+    :62-75) on 100 real + 20 complex parameters: the runtime-dimension set has no shared-factor form for such a space, the engine
+    proposes from the per-chain factor field -- every chain's copy holds chol of the initial matrices -- from the first step on,
+    and switches to the chains' own running covariances after 50 measures like any other engine."""
+    nr, nc, n, seed = 100, 20, 70, 81
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((nr, nr))
+    cov_r = 0.5 * np.identity(nr) + 0.3 * a @ a.T / nr
+    b = rng.standard_normal((nc, nc)) + 1j * rng.standard_normal((nc, nc))
+    cov_c = 0.8 * np.identity(nc) + 0.2 * b @ b.conj().T / nc
+    real_w, cplx_w = tuple(np.linspace(0.5, 2.0, nr)), tuple(np.linspace(0.7, 1.6, nc))
+    x0, z0 = list(np.linspace(-0.2, 0.2, nr)), list(0.1 * np.exp(0.7j * np.arange(nc)))
+    eng = me.MetropolisEngine(me.DiagQuadratic(real_w, cplx_w), None, x0, z0, temp=1.0, n_chains=n, seed=seed, dtype="f64",
+                              sampling_width=0.05, covariance_matrix_real=cov_r, covariance_matrix_complex=cov_c)
+    ora = ManyChainOracle(nr, nc, energies.diag_quadratic(nr, nc, real_w, cplx_w), n, seed=seed, temp=1.0,
+                          initial_real_params=x0, initial_complex_params=z0, sampling_width=0.05,
+                          covariance_matrix_real=cov_r, covariance_matrix_complex=cov_c)
+    eng.step_all(3)
+    ora.step(3)
+    assert np.allclose(eng._get(0), ora.x, rtol=0, atol=1e-9)
+    assert eng.accept_stats() == (ora.accepted, ora.proposed)
+    eng.step_real_group()
+    ora.step(1, group="real")
+    for k in range(52):
+        eng.step_all(1)
+        ora.step(1)
+        eng.measure()
+        ora.measure()
+    eng.step_all(2)
+    ora.step(2)
+    assert np.allclose(eng._get(0), ora.x, rtol=0, atol=1e-8)
+    assert np.allclose(eng.covariance_matrix_complex, ora.cov_complex, rtol=0, atol=1e-9)
+    assert eng.accept_stats() == (ora.accepted, ora.proposed)
