@@ -1185,11 +1185,33 @@ int enqueue_pooled_moments(me_engine *e, void *device_out, int64_t n_doubles) {
 }
 }  // namespace
 
+// Waits for `ev`, polling for the first two milliseconds.  hipEventSynchronize gives up its own active wait after a few
+// microseconds and blocks; the thread is then woken by an interrupt, and on a host that is otherwise idle (one OpenMP
+// thread, as torch.distributed.run sets it) the core has gone to sleep by then: the overlapped config 5 loop, whose host side
+// is 85 us per cycle, ran 3-5 x slower there.
+static hipError_t wait_polling(hipEvent_t ev) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t rc = hipEventQuery(ev);
+    if (rc != hipErrorNotReady) return rc;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipEventSynchronize(ev);
+  }
+}
+// the same for everything queued on a stream
+static hipError_t wait_polling(hipStream_t stream) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t rc = hipStreamQuery(stream);
+    if (rc != hipErrorNotReady) return rc;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipStreamSynchronize(stream);
+  }
+}
+
 int me_pooled_moments_device(me_engine *e, void *device_out, int64_t n_doubles) {
   if (!e || !device_out) return ME_ERR_INVALID;
   int rc = enqueue_pooled_moments(e, device_out, n_doubles);
   if (rc != ME_OK) return rc;
-  ME_HIP(e, hipStreamSynchronize(e->stream));
+  ME_HIP(e, wait_polling(e->stream));
   return ME_OK;
 }
 
@@ -1199,7 +1221,7 @@ int me_pooled_moments(me_engine *e, double *host_out, int64_t n_doubles) {
   if (rc != ME_OK) return rc;
   // through a pinned staging buffer: one asynchronous copy behind the kernels, one wait
   ME_HIP(e, hipMemcpyAsync(e->pool_host, e->pool_dev, sizeof(double) * (size_t)n_doubles, hipMemcpyDeviceToHost, e->stream));
-  ME_HIP(e, hipStreamSynchronize(e->stream));
+  ME_HIP(e, wait_polling(e->stream));
   std::memcpy(host_out, e->pool_host, sizeof(double) * (size_t)n_doubles);
   return ME_OK;
 }
@@ -1311,19 +1333,6 @@ int me_comm_info(me_engine *e, int32_t *rank, int32_t *world, int32_t *rccl_vers
     *rccl_version = v;
   }
   return ME_OK;
-}
-
-// Waits for `ev`, polling for the first two milliseconds.  hipEventSynchronize gives up its own active wait after a few
-// microseconds and blocks; the thread is then woken by an interrupt, and on a host that is otherwise idle (one OpenMP
-// thread, as torch.distributed.run sets it) the core has gone to sleep by then: the overlapped config 5 loop, whose host side
-// is 85 us per cycle, ran 3-5 x slower there.
-static hipError_t wait_polling(hipEvent_t ev) {
-  const auto t0 = std::chrono::steady_clock::now();
-  for (;;) {
-    const hipError_t rc = hipEventQuery(ev);
-    if (rc != hipErrorNotReady) return rc;
-    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipEventSynchronize(ev);
-  }
 }
 
 int me_pooled_moments_end(me_engine *e, double *host_out, int64_t n_doubles) {
