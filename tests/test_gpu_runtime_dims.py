@@ -360,3 +360,28 @@ def test_initial_covariance_with_per_chain_shapes_at_runtime_dimensions():
     assert np.allclose(eng._get(0), ora.x, rtol=0, atol=1e-8)
     assert np.allclose(eng.covariance_matrix_complex, ora.cov_complex, rtol=0, atol=1e-9)
     assert eng.accept_stats() == (ora.accepted, ora.proposed)
+
+
+def test_checkpoint_round_trip_with_per_chain_shapes_at_runtime_dimensions():
+    """state_dict / load_state_dict of a 100 real + 20 complex engine in cov_mode="reference" (per-chain covariance and factor
+    fields of the runtime-dimension set included): the resumed engine continues the uninterrupted trajectory bit for bit, both
+    when the checkpoint is taken before the 50-measure threshold and after it."""
+    nr, nc = 100, 20
+    args = (me.DiagQuadratic(tuple(np.linspace(0.5, 2.0, nr)), tuple(np.linspace(0.7, 1.6, nc))), None, [0.05] * nr, [0.05j] * nc)
+    kw = dict(temp=1.0, n_chains=130, seed=19, dtype="f64", sampling_width=0.06)
+    for measures_before in (20, 53):
+        a = me.MetropolisEngine(*args, **kw)
+        for _ in range(measures_before):
+            a.step_all(1)
+            a.measure()
+        state = a.state_dict()
+        b = me.MetropolisEngine(*args, **kw)
+        b.load_state_dict(state)
+        for eng in (a, b):
+            for _ in range(35 if measures_before < 50 else 3):      # the first engine crosses the threshold after the restart
+                eng.step_all(2)
+                eng.measure()
+            eng.step_complex_group()
+        for field in range(7):
+            assert np.array_equal(a._get(field), b._get(field)), (measures_before, field)
+        assert a.accept_stats() == b.accept_stats()
