@@ -385,3 +385,20 @@ def test_checkpoint_round_trip_with_per_chain_shapes_at_runtime_dimensions():
         for field in range(7):
             assert np.array_equal(a._get(field), b._get(field)), (measures_before, field)
         assert a.accept_stats() == b.accept_stats()
+
+
+def test_cycle_on_the_runtime_dimension_set_is_step_all_plus_measure():
+    """engine.cycle(k) where no one-launch kernel exists (the runtime-dimension set): me_cycle issues the step launch and the
+    measure launch itself -- same state, statistics and per-chain shapes as step_all(k); measure(), across the threshold."""
+    nr = 140
+    args = (me.DiagQuadratic(tuple(np.linspace(0.5, 2.0, nr))), None, [0.02] * nr, None)
+    kw = dict(temp=1.0, n_chains=100, seed=23, dtype="f64", sampling_width=0.06)
+    a, b = me.MetropolisEngine(*args, **kw), me.MetropolisEngine(*args, **kw)
+    for _ in range(54):
+        a.cycle(2)
+        b.step_all(2)
+        b.measure()
+    assert a.fused_cycles() == 0
+    for field in range(7):
+        assert np.array_equal(a._get(field), b._get(field)), field
+    assert a.accept_stats() == b.accept_stats()
