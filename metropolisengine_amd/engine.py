@@ -17,6 +17,10 @@ marshals arguments and unpacks results.  Differences from the reference, all for
  * with ``n_chains == 1`` attributes have the reference's shapes and ``step_all()`` returns a bool; with more
    chains they gain a leading chain axis and ``step_all()`` returns ``None`` (it stays asynchronous).
  * randomness is a seeded counter-based Philox stream per global chain id instead of numpy's global state.
+ * parameter-space size: like the reference, no fixed limit on the number of parameters -- up to 96 real degrees of freedom
+   (``n_real + 2 n_complex``) the register-resident kernels, up to 128 a kernel set compiled on first use for the default
+   ``cov_mode="reference"``, beyond that the runtime-dimension kernels (identity shape or per-chain shapes for any space, one
+   shared factor for pure real ones) as long as 64 x D values fit the LDS (float64: D <= 290); README.md "Limits".
 """
 import ctypes
 
@@ -201,9 +205,9 @@ class MetropolisEngine:
                 # dimensions outside the prebuilt set: compile this (nr, nc) kernel set once (hipcc) and load it
                 _capi.check(self._lib.me_load_plugin(build.build_dims(nr, nc).encode()))
             elif build.MAX_REGISTER_DOF < d <= build.MAX_COMPILED_DOF and cov_mode == "reference":
-                # beyond 96 degrees of freedom the runtime-dimension set (no build) has per-chain shapes for pure real spaces
-                # only, and slower ones: up to MAX_COMPILED_DOF the space's own kernel set is compiled after all for the
-                # reference's semantics (streamed shapes, real / mixed / complex spaces alike; minutes of hipcc, cached)
+                # beyond 96 degrees of freedom the runtime-dimension set (no build) has per-chain shapes too, slower ones per
+                # step: up to MAX_COMPILED_DOF the space's own kernel set is compiled after all for the reference's
+                # semantics (streamed shapes; minutes of hipcc, cached)
                 _capi.check(self._lib.me_load_plugin(build.build_dims(nr, nc).encode()))
         _capi.check(self._lib.me_create(ctypes.byref(cfg), ctypes.byref(handle)))
         self._handle = handle
