@@ -47,3 +47,14 @@ def test_readme_example_with_its_python_lambda(capsys):
     assert abs(x.var() / 0.005 - 1.0) < 0.1 and abs(x.mean()) < 6 * np.sqrt(0.005 / (1 << 14))      # Var x = T / 2
     assert many.fused_cycles() == 30
     assert "ensemble of" in capsys.readouterr().out
+
+
+def test_large_space_demo(capsys):
+    """150 real parameters on the runtime-dimension set: the default per-chain adaptive shapes run (the reference's recursion,
+    reproduced as it is), and one shape pooled over the ensemble brings the ensemble covariance to T/2 A^-1."""
+    per_chain, pooled, err_ref, err_pool = _load("demo_large_space").main(n_chains=1 << 11, cycles=70, sweeps_per_cycle=20)
+    assert per_chain.cov_mode == "reference" and per_chain.measure_step_counter == 71
+    assert per_chain.covariance_matrix_real.shape == (1 << 11, 150, 150)
+    assert 0.05 < per_chain.acceptance_rate() < 0.7 and err_ref < 1.0
+    assert pooled.shared_factor() is not None and err_pool < 0.15
+    assert "pooled over the ensemble" in capsys.readouterr().out
